@@ -1,0 +1,148 @@
+/* t2p.h -- C ABI of libt2p_hip.so: the text2protein reverse-diffusion sampling path on MI355X.
+ *
+ * The reference (szhan227/text2protein) has no FFI layer; its seam for this path is a set of
+ * Python callables.  Each entry point below names the reference
+ * interface it stands in for.  All pointers marked "device" are HIP device pointers owned by
+ * the caller; nothing is retained beyond the call unless stated.  `stream` is a hipStream_t
+ * passed as void* (NULL = the default stream).  Every function returns 0 on success or a
+ * non-zero status; t2p_last_error() then returns a message for the calling thread.
+ * There is no CPU fallback: every compute entry point launches HIP kernels.
+ */
+#ifndef T2P_H_
+#define T2P_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2P_DTYPE_F32 0   /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32)      */
+#define T2P_DTYPE_BF16 1  /* bf16 operands, fp32 accumulate                */
+#define T2P_DTYPE_F16 2   /* fp16 operands, fp32 accumulate                */
+
+#define T2P_SDE_VE 0
+#define T2P_SDE_VP 1
+
+/* Flat view of the YAML keys the score network reads
+ * (reference score_sde_pytorch/models/ncsnpp.py:74-217, configs/test_config.yml). */
+typedef struct t2p_model_config {
+  int32_t num_channels;        /* data.num_channels                        */
+  int32_t max_res_num;         /* data.max_res_num (map side L)            */
+  int32_t nf;                  /* model.nf                                 */
+  int32_t num_res_blocks;      /* model.num_res_blocks                     */
+  int32_t n_ch_mult;           /* len(model.ch_mult), <= 8                 */
+  int32_t ch_mult[8];
+  int32_t n_attn_resolutions;  /* len(model.attn_resolutions), <= 8        */
+  int32_t attn_resolutions[8];
+  int32_t n_heads;             /* model.n_heads                            */
+  int32_t context_dim;         /* model.context_dim                        */
+  int32_t num_scales;          /* model.num_scales (N)                     */
+  double sigma_min, sigma_max; /* model.sigma_{min,max}                    */
+  int32_t skip_rescale;        /* model.skip_rescale                       */
+  int32_t scale_by_sigma;      /* model.scale_by_sigma                     */
+  int32_t compute_dtype;       /* T2P_DTYPE_*                              */
+} t2p_model_config;
+
+typedef struct t2p_engine t2p_engine;    /* the score network: UNetModel (ncsnpp.py:71-263) */
+typedef struct t2p_sampler t2p_sampler;  /* the PC loop: get_pc_sampler (sampling.py:213-291) */
+
+const char* t2p_last_error(void);
+/* number of visible HIP devices, or -1 (no driver / no GPU).  Does not create a context. */
+int t2p_device_count(void);
+
+/* ---- score network ------------------------------------------------------------------------
+ * t2p_engine_create      <- UNetModel.__init__ / get_model   (ncsnpp.py:74-217, score_sde_pytorch/utils.py:4-9)
+ * t2p_engine_load_param  <- load_state_dict of one tensor    (score_sde_pytorch/utils.py:14);
+ *                           `name` is the reference state-dict key, with or without "module."
+ * t2p_engine_finalize    <- end of restore_checkpoint: fails if any tensor is missing
+ * t2p_engine_set_context <- the `context=` argument          (sampling_6d.py:137,152): projects
+ *                           the frozen text embedding through every to_k / to_v once
+ * t2p_engine_score       <- model(x, labels, context)        (ncsnpp.py:220-263)                  */
+int t2p_engine_create(const t2p_model_config* cfg, t2p_engine** out);
+void t2p_engine_destroy(t2p_engine* e);
+int t2p_engine_num_params(const t2p_engine* e);
+/* name and shape (ndim <= 4) of expected tensor i, in reference parameters() order */
+int t2p_engine_param_info(const t2p_engine* e, int i, const char** name, int64_t shape[4], int* ndim);
+int t2p_engine_load_param(t2p_engine* e, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int t2p_engine_finalize(t2p_engine* e);
+/* context: device fp32 [batch][tokens][context_dim] */
+int t2p_engine_set_context(t2p_engine* e, const float* context, int batch, int tokens, void* stream);
+/* x: device fp32 (batch, C, L, L); labels: device int32 [batch] time labels (index into the
+ * descending sigma table); out: device fp32 (batch, C, L, L) = network output / sigma[label]. */
+int t2p_engine_score(t2p_engine* e, const float* x, const int32_t* labels, float* out, int batch, void* stream);
+/* bytes of device memory currently held (weights + cached activations) */
+int64_t t2p_engine_device_bytes(const t2p_engine* e);
+
+/* ---- predictor-corrector sampler ------------------------------------------------------------
+ * t2p_sampler_create        <- get_sampling_fn / get_pc_sampler (sampling.py:78-104, 213-243)
+ * t2p_sampler_set_condition <- what sampling.py:259-277 reduces `condition` to:
+ *                              conditional_mask (1 = evolves) and x_initial
+ * t2p_sampler_step          <- one iteration of the loop body  (sampling.py:279-285)
+ * t2p_sampler_run           <- pc_sampler(model, condition, context) (sampling.py:245-289)         */
+typedef struct t2p_sampler_config {
+  int32_t sde;               /* T2P_SDE_VE (every shipped config) or T2P_SDE_VP                  */
+  int32_t N;                 /* sde.N = model.num_scales                                          */
+  double sigma_min, sigma_max, beta_min, beta_max;
+  double snr;                /* sampling.snr                                                      */
+  int32_t n_steps_each;      /* sampling.n_steps_each                                             */
+  int32_t probability_flow;  /* sampling.probability_flow                                         */
+  int32_t denoise;           /* sampling.noise_removal                                            */
+  double eps;                /* integrate to eps (1e-5 for VE, sampling_6d.py:79)                 */
+  int32_t batch;             /* chains held by this process                                       */
+  int32_t global_batch;      /* chains the Langevin batch-mean runs over (>= batch; == batch unless
+                                the caller all-reduces the norm sums itself)                      */
+  uint64_t seed;             /* on-device Philox noise                                            */
+} t2p_sampler_config;
+
+/* g_table: optional host float[N], G_i of step i as the reference computes it in float32
+ * (sde_lib.py:237-245); NULL = computed here in double. */
+int t2p_sampler_create(t2p_engine* e, const t2p_sampler_config* cfg, const float* g_table, t2p_sampler** out);
+void t2p_sampler_destroy(t2p_sampler* s);
+/* mask: device uint8 (B,C,L,L), 1 where the chain evolves; x_initial: device fp32; both NULL = unconditional */
+int t2p_sampler_set_condition(t2p_sampler* s, const uint8_t* mask, const float* x_initial);
+/* reset the device step counter to `step` (0 at the start of a run) */
+int t2p_sampler_reset(t2p_sampler* s, int step, void* stream);
+/* One PC step at the current step index, in place on x (device fp32 (B,C,L,L)); x_mean receives the
+ * predictor's mean.  noise_corrector / noise_predictor: device standard-normal draws to use
+ * (parity runs); NULL = generate on device. */
+int t2p_sampler_step(t2p_sampler* s, float* x, float* x_mean, const float* noise_corrector,
+                     const float* noise_predictor, void* stream);
+/* Full run: x must hold the (already conditioned) prior sample on entry when `prior_given`, else it
+ * is drawn on device (randn * sigma_max, then mask applied).  out receives x_mean (denoise) or x. */
+int t2p_sampler_run(t2p_sampler* s, float* x, float* out, int prior_given, int n_steps, void* stream);
+
+/* ---- individual operators (parity tests call these through the same ABI) -------------------- */
+int t2p_op_gemm(int dtype, const void* A, int a_f32, const void* Bw, void* C, int c_f32, int M, int N, int K,
+                int64_t lda, int64_t ldb, int64_t ldc, const float* bias_n, const float* residual, float alpha,
+                void* stream);
+/* x: NHWC in the given layout; w: [Cout][3][3][Cin] compute dtype; out fp32 NHWC */
+int t2p_op_conv3x3(int dtype, const void* x, int a_f32, const void* w, const float* bias, float* out, int batch,
+                   int H, int W, int Cin, int Cout, int upsample, void* stream);
+int t2p_op_groupnorm(const float* x0, const float* x1, int C0, int C1, int batch, int H, int W, int groups,
+                     const float* gamma, const float* beta, float eps, int silu, int down, void* out, int dtype,
+                     void* stream);
+int t2p_op_layernorm(const float* x, const float* gamma, const float* beta, void* out, int dtype, int64_t rows,
+                     int C, float eps, void* stream);
+int t2p_op_softmax(const float* S, int64_t lds, void* P, int64_t ldp, int dtype, int64_t rows, int n, float scale,
+                   void* stream);
+int t2p_op_geglu(const float* u, void* out, int dtype, int64_t rows, int inner, void* stream);
+/* q: [B][nq][ldq], k: [B][nk][ldk] (head h at column h*d), vt: [B][heads*d][ldvt]; out [B][nq][heads*d].
+ * Operands in compute dtype; scores/softmax in fp32.  workspace sizes via t2p_op_attention_ws. */
+int64_t t2p_op_attention_ws(int dtype, int batch, int heads, int nq, int nk);
+int t2p_op_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt,
+                     int64_t ldvt, void* out, int batch, int heads, int nq, int nk, int d, float scale,
+                     void* workspace, void* stream);
+int t2p_op_langevin(const float* x, const float* grad, const float* noise, const uint8_t* mask,
+                    const float* x_initial, float* x_out, float* x_mean_out, int batch, int64_t per_sample,
+                    float snr, float alpha, float* sums_out /* device float[2], may be NULL */, void* stream);
+int t2p_op_predictor(const float* x, const float* score, const float* noise, const uint8_t* mask,
+                     const float* x_initial, float* x_out, float* x_mean_out, int64_t n, float G,
+                     int probability_flow, void* stream);
+int t2p_op_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+int t2p_op_convert(const float* in, void* out, int dtype, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2P_H_ */

@@ -1,0 +1,221 @@
+"""Per-operator parity of the HIP kernels (called through the C ABI) against torch fp32 on CPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 2e-6, 1: 6e-3, 2: 8e-4}     # rel-L2 per op: exact-f32 MFMA, bf16, fp16 operands
+TDT = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from text2protein_amd import _lib
+    return _lib.load()
+
+
+def dev(t):
+    return t.contiguous().to("cuda")
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def check(lib, rc):
+    assert rc == 0, lib.t2p_last_error().decode()
+
+
+@pytest.mark.parametrize("dt", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 72, 40), (1000, 515, 264), (64, 5, 32), (7, 130, 8)])
+def test_gemm(lib, dt, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    ref = (a.double() @ w.double().T + bias.double() + res.double()) * 0.5
+    da, dw = dev(a), dev(w.to(TDT[dt]))
+    out = torch.empty(M, N, device="cuda")
+    check(lib, lib.t2p_op_gemm(dt, P(da), 1, P(dw), P(out), 1, M, N, K, K, K, N, P(dev(bias)), P(dev(res)), 0.5, None))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), ref) < TOL[dt]
+    if dt:   # operands already in the compute dtype, compute-dtype output
+        da16 = dev(a.to(TDT[dt]))
+        out16 = torch.empty(M, N, device="cuda", dtype=TDT[dt])
+        check(lib, lib.t2p_op_gemm(dt, P(da16), 0, P(dw), P(out16), 0, M, N, K, K, K, N, None, None, 1.0, None))
+        torch.cuda.synchronize()
+        assert rel_l2(out16.float().cpu(), a.double() @ w.double().T) < 2 * TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [0, 1, 2])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,up", [(2, 16, 16, 32, 64, 0), (1, 8, 12, 96, 32, 0), (2, 8, 8, 64, 40, 1),
+                                              (3, 4, 4, 8, 5, 0), (1, 32, 32, 264, 136, 0)])
+def test_conv3x3(lib, dt, B, H, W, Cin, Cout, up):
+    g = torch.Generator().manual_seed(H * 31 + Cin)
+    hs, ws = (H // 2, W // 2) if up else (H, W)
+    x = torch.randn(B, Cin, hs, ws, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    xin = x.repeat_interleave(2, 2).repeat_interleave(2, 3) if up else x
+    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    dx = dev(x.permute(0, 2, 3, 1))
+    dw = dev(w.permute(0, 2, 3, 1).to(TDT[dt]))
+    out = torch.empty(B, H, W, Cout, device="cuda")
+    check(lib, lib.t2p_op_conv3x3(dt, P(dx), 1, P(dw), P(dev(b)), P(out), B, H, W, Cin, Cout, up, None))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("C0,C1,G,silu,down", [(32, 0, 8, 1, 0), (64, 32, 24, 1, 0), (512, 256, 32, 0, 0),
+                                               (64, 0, 16, 1, 1), (1024, 1024, 32, 1, 0), (1024, 512, 32, 0, 0)])
+def test_groupnorm(lib, C0, C1, G, silu, down):
+    B, H, W = 2, 8, 6
+    g = torch.Generator().manual_seed(C0 + C1)
+    x = torch.randn(B, C0 + C1, H, W, generator=g) * 2 + 0.5
+    gamma = torch.randn(C0 + C1, generator=g)
+    beta = torch.randn(C0 + C1, generator=g)
+    ref = F.group_norm(x.double(), G, gamma.double(), beta.double(), eps=1e-6)
+    if silu:
+        ref = F.silu(ref)
+    if down:
+        ref = ref.reshape(B, C0 + C1, H // 2, 2, W // 2, 2).mean(dim=(3, 5))
+    ref = ref.permute(0, 2, 3, 1)
+    xn = x.permute(0, 2, 3, 1)
+    x0 = dev(xn[..., :C0])
+    x1 = dev(xn[..., C0:]) if C1 else None
+    for dt in (0, 1, 2):
+        out = torch.empty(ref.shape, device="cuda", dtype=TDT[dt])
+        check(lib, lib.t2p_op_groupnorm(P(x0), P(x1) if C1 else None, C0, C1, B, H, W, G, P(dev(gamma)), P(dev(beta)),
+                                        1e-6, silu, down, P(out), dt, None))
+        torch.cuda.synchronize()
+        assert rel_l2(out.float().cpu(), ref) < (3e-6 if dt == 0 else (5e-3 if dt == 1 else 6e-4))
+
+
+def test_groupnorm_large_mean(lib):
+    """E[x^2]-E[x]^2 is combined in double across blocks: a large mean must not wreck the variance."""
+    B, H, W, C, G = 1, 32, 32, 64, 16
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, H, W, generator=g) + 30.0
+    ones, zeros = torch.ones(C), torch.zeros(C)
+    ref = F.group_norm(x.double(), G, ones.double(), zeros.double(), eps=1e-6).permute(0, 2, 3, 1)
+    out = torch.empty(ref.shape, device="cuda")
+    check(lib, lib.t2p_op_groupnorm(P(dev(x.permute(0, 2, 3, 1))), None, C, 0, B, H, W, G, P(dev(ones)), P(dev(zeros)),
+                                    1e-6, 0, 0, P(out), 0, None))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), ref) < 2e-4
+
+
+@pytest.mark.parametrize("rows,C", [(10, 64), (1000, 512), (3, 1024)])
+def test_layernorm(lib, rows, C):
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(rows, C, generator=g) * 3 + 1
+    ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.layer_norm(x.double(), (C,), ga.double(), be.double(), eps=1e-5)
+    out = torch.empty(rows, C, device="cuda")
+    check(lib, lib.t2p_op_layernorm(P(dev(x)), P(dev(ga)), P(dev(be)), P(out), 0, rows, C, 1e-5, None))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("rows,n", [(9, 3), (64, 64), (100, 1000), (5, 1500)])
+def test_softmax(lib, rows, n):
+    g = torch.Generator().manual_seed(n)
+    ld = (n + 7) // 8 * 8
+    S = torch.randn(rows, ld, generator=g) * 4
+    ref = torch.softmax(S[:, :n].double() * 0.3, dim=-1)
+    out = torch.full((rows, ld), 7.0, device="cuda")
+    check(lib, lib.t2p_op_softmax(P(dev(S)), ld, P(out), ld, 0, rows, n, 0.3, None))
+    torch.cuda.synchronize()
+    o = out.cpu()
+    assert rel_l2(o[:, :n], ref) < 2e-6
+    assert float(o[:, n:].abs().max()) == 0.0 if ld > n else True
+
+
+def test_geglu(lib):
+    g = torch.Generator().manual_seed(3)
+    u = torch.randn(50, 512, generator=g) * 2
+    a, gate = u.double().chunk(2, dim=-1)
+    ref = a * F.gelu(gate)
+    out = torch.empty(50, 256, device="cuda")
+    check(lib, lib.t2p_op_geglu(P(dev(u)), P(out), 0, 50, 256, None))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("dt", [0, 1, 2])
+@pytest.mark.parametrize("B,heads,nq,nk,d", [(2, 4, 64, 64, 16), (1, 8, 256, 77, 64), (2, 1, 64, 64, 256), (2, 2, 4, 3, 32)])
+def test_attention(lib, dt, B, heads, nq, nk, d):
+    g = torch.Generator().manual_seed(nq + nk)
+    C_ = heads * d
+    q = torch.randn(B, nq, C_, generator=g)
+    k = torch.randn(B, nk, C_, generator=g)
+    v = torch.randn(B, nk, C_, generator=g)
+    scale = d ** -0.5
+    td = TDT[dt]
+    qr, kr, vr = (t.to(td).double() for t in (q, k, v))    # reference on the rounded operands
+    qh = qr.reshape(B, nq, heads, d).transpose(1, 2)
+    kh = kr.reshape(B, nk, heads, d).transpose(1, 2)
+    vh = vr.reshape(B, nk, heads, d).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(B, nq, C_)
+    nkp = (nk + 7) // 8 * 8
+    vt = torch.zeros(B, C_, nkp)
+    vt[:, :, :nk] = v.transpose(1, 2)
+    vt[:, :, nk:] = float("nan") if nkp > nk else 0.0     # padding must never leak into the result
+    ws = torch.empty(lib.t2p_op_attention_ws(dt, B, heads, nq, nk), dtype=torch.uint8, device="cuda")
+    out = torch.empty(B, nq, C_, device="cuda", dtype=td)
+    check(lib, lib.t2p_op_attention(dt, P(dev(q.to(td))), C_, P(dev(k.to(td))), C_, P(dev(vt.to(td))), nkp, P(out), B, heads,
+                                    nq, nk, d, scale, P(ws), None))
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu(), ref) < (3e-6 if dt == 0 else (8e-3 if dt == 1 else 1e-3))
+
+
+def test_langevin_and_predictor(lib):
+    from oracle import t2p_oracle as O
+    g = torch.Generator().manual_seed(11)
+    B, Cc, L = 3, 5, 16
+    x = torch.randn(B, Cc, L, L, generator=g) * 50
+    grad = torch.randn(B, Cc, L, L, generator=g) * 0.02
+    noise = torch.randn(B, Cc, L, L, generator=g)
+    mask = torch.rand(B, Cc, L, L, generator=g) > 0.3
+    x0 = torch.randn(B, Cc, L, L, generator=g)
+    rx, rxm = O.langevin_update(x, grad.double(), noise, 0.17)
+    rx = torch.where(mask, rx, x0.double())
+    ox, oxm = torch.empty_like(x, device="cuda"), torch.empty_like(x, device="cuda")
+    sums = torch.zeros(2, device="cuda")
+    check(lib, lib.t2p_op_langevin(P(dev(x)), P(dev(grad)), P(dev(noise)), P(dev(mask.to(torch.uint8))), P(dev(x0)), P(ox),
+                                   P(oxm), B, Cc * L * L, 0.17, 1.0, P(sums), None))
+    torch.cuda.synchronize()
+    assert rel_l2(ox.cpu(), rx) < 1e-6 and rel_l2(oxm.cpu(), rxm) < 1e-6
+    s = sums.cpu().double()
+    assert abs(float(s[0]) - float(grad.reshape(B, -1).norm(dim=-1).sum())) < 1e-4
+    assert abs(float(s[1]) / float(noise.reshape(B, -1).norm(dim=-1).sum()) - 1) < 1e-6
+    G = torch.full((B,), 3.7)
+    for pf in (0, 1):
+        rx, rxm = O.reverse_diffusion_update(x, grad.double(), noise, G, bool(pf))
+        check(lib, lib.t2p_op_predictor(P(dev(x)), P(dev(grad)), P(dev(noise)), None, None, P(ox), P(oxm), x.numel(), 3.7, pf, None))
+        torch.cuda.synchronize()
+        assert rel_l2(ox.cpu(), rx) < 1e-6 and rel_l2(oxm.cpu(), rxm) < 1e-6
+
+
+def test_philox_normal_moments(lib):
+    n = 1 << 20
+    out = torch.empty(n, device="cuda")
+    check(lib, lib.t2p_op_philox_normal(P(out), n, 1234, 1, None))
+    out2 = torch.empty(n, device="cuda")
+    check(lib, lib.t2p_op_philox_normal(P(out2), n, 1234, 2, None))
+    torch.cuda.synchronize()
+    z = out.cpu().double()
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1) < 5e-3
+    assert abs(float((z ** 4).mean()) - 3) < 0.05
+    assert abs(float((z * out2.cpu().double()).mean())) < 5e-3       # streams are independent
+    out3 = torch.empty(n, device="cuda")
+    check(lib, lib.t2p_op_philox_normal(P(out3), n, 1234, 1, None))
+    torch.cuda.synchronize()
+    assert torch.equal(out, out3)                                     # counter-based: reproducible

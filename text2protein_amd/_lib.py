@@ -1,0 +1,117 @@
+"""ctypes binding of libt2p_hip.so (C ABI: include/t2p.h).
+
+There is no fallback: if the library is missing or a call fails, a ``T2PError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+DTYPE_NAMES = {"f32": DT_F32, "fp32": DT_F32, "float32": DT_F32, "bf16": DT_BF16, "bfloat16": DT_BF16,
+               "f16": DT_F16, "fp16": DT_F16, "float16": DT_F16}
+SDE_VE, SDE_VP = 0, 1
+
+
+class T2PError(RuntimeError):
+    pass
+
+
+class ModelConfig(C.Structure):
+    _fields_ = [("num_channels", C.c_int32), ("max_res_num", C.c_int32), ("nf", C.c_int32),
+                ("num_res_blocks", C.c_int32), ("n_ch_mult", C.c_int32), ("ch_mult", C.c_int32 * 8),
+                ("n_attn_resolutions", C.c_int32), ("attn_resolutions", C.c_int32 * 8),
+                ("n_heads", C.c_int32), ("context_dim", C.c_int32), ("num_scales", C.c_int32),
+                ("sigma_min", C.c_double), ("sigma_max", C.c_double),
+                ("skip_rescale", C.c_int32), ("scale_by_sigma", C.c_int32), ("compute_dtype", C.c_int32)]
+
+
+class SamplerConfig(C.Structure):
+    _fields_ = [("sde", C.c_int32), ("N", C.c_int32),
+                ("sigma_min", C.c_double), ("sigma_max", C.c_double), ("beta_min", C.c_double), ("beta_max", C.c_double),
+                ("snr", C.c_double), ("n_steps_each", C.c_int32), ("probability_flow", C.c_int32),
+                ("denoise", C.c_int32), ("eps", C.c_double), ("batch", C.c_int32), ("global_batch", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
+_vp, _i, _i64, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes); every symbol declared in include/t2p.h
+SIGNATURES = {
+    "t2p_last_error": (C.c_char_p, []),
+    "t2p_device_count": (_i, []),
+    "t2p_engine_create": (_i, [C.POINTER(ModelConfig), C.POINTER(_vp)]),
+    "t2p_engine_destroy": (None, [_vp]),
+    "t2p_engine_num_params": (_i, [_vp]),
+    "t2p_engine_param_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i)]),
+    "t2p_engine_load_param": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
+    "t2p_engine_finalize": (_i, [_vp]),
+    "t2p_engine_set_context": (_i, [_vp, _vp, _i, _i, _vp]),
+    "t2p_engine_score": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "t2p_engine_device_bytes": (_i64, [_vp]),
+    "t2p_sampler_create": (_i, [_vp, C.POINTER(SamplerConfig), _vp, C.POINTER(_vp)]),
+    "t2p_sampler_destroy": (None, [_vp]),
+    "t2p_sampler_set_condition": (_i, [_vp, _vp, _vp]),
+    "t2p_sampler_reset": (_i, [_vp, _i, _vp]),
+    "t2p_sampler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "t2p_sampler_run": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "t2p_op_gemm": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _vp, _f, _vp]),
+    "t2p_op_conv3x3": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "t2p_op_groupnorm": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
+    "t2p_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp]),
+    "t2p_op_softmax": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i, _f, _vp]),
+    "t2p_op_geglu": (_i, [_vp, _vp, _i, _i64, _i, _vp]),
+    "t2p_op_attention_ws": (_i64, [_i, _i, _i, _i, _i]),
+    "t2p_op_attention": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "t2p_op_langevin": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp]),
+    "t2p_op_predictor": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _i, _vp]),
+    "t2p_op_philox_normal": (_i, [_vp, _i64, _u64, _u64, _vp]),
+    "t2p_op_convert": (_i, [_vp, _vp, _i, _i64, _vp]),
+}
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True):
+    """dlopen libt2p_hip.so (building it first when the sources are newer)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if build_if_missing and _build.needs_build():
+        try:
+            _build.build(verbose=False)
+        except Exception as e:  # noqa: BLE001
+            if not os.path.exists(path):
+                raise T2PError(f"libt2p_hip.so is missing and could not be built: {e}") from e
+    if not os.path.exists(path):
+        raise T2PError(f"{path} not found: run `python -m text2protein_amd.build` (needs hipcc)")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().t2p_last_error()
+        raise T2PError(f"libt2p_hip call failed (status {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

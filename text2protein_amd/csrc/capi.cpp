@@ -1,0 +1,285 @@
+// extern "C" surface of libt2p_hip.so (declarations and reference citations: include/t2p.h).
+#include <new>
+
+#include "engine.h"
+
+using namespace t2p;
+
+#define API_BEGIN try {
+#define API_END                                        \
+  }                                                    \
+  catch (const std::bad_alloc&) {                      \
+    set_last_error("out of host memory");              \
+    return T2P_ERR_STATE;                              \
+  }                                                    \
+  catch (const std::exception& ex) {                   \
+    set_last_error(std::string("exception: ") + ex.what()); \
+    return T2P_ERR_STATE;                              \
+  }
+
+extern "C" {
+
+const char* t2p_last_error(void) { return get_last_error(); }
+
+int t2p_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  return n;
+}
+
+int t2p_engine_create(const t2p_model_config* cfg, t2p_engine** out) {
+  API_BEGIN
+  T2P_REQUIRE(cfg && out, "null argument");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_last_error("no HIP device: libt2p_hip has no CPU fallback");
+    return T2P_ERR_HIP;
+  }
+  t2p_engine* e = new t2p_engine(*cfg);
+  int rc = e->impl.build();
+  if (rc != T2P_OK) {
+    delete e;
+    return rc;
+  }
+  *out = e;
+  return T2P_OK;
+  API_END
+}
+
+void t2p_engine_destroy(t2p_engine* e) { delete e; }
+
+int t2p_engine_num_params(const t2p_engine* e) { return e ? (int)e->impl.params().size() : 0; }
+
+int t2p_engine_param_info(const t2p_engine* e, int i, const char** name, int64_t shape[4], int* ndim) {
+  API_BEGIN
+  T2P_REQUIRE(e && name && shape && ndim, "null argument");
+  const auto& ps = e->impl.params();
+  T2P_REQUIRE(i >= 0 && i < (int)ps.size(), "parameter index out of range");
+  *name = ps[i].name.c_str();
+  *ndim = (int)ps[i].shape.size();
+  for (int k = 0; k < 4; ++k) shape[k] = k < *ndim ? ps[i].shape[k] : 1;
+  return T2P_OK;
+  API_END
+}
+
+int t2p_engine_load_param(t2p_engine* e, const char* name, const float* host_data, const int64_t* shape, int ndim) {
+  API_BEGIN
+  T2P_REQUIRE(e, "null engine");
+  return e->impl.load_param(name, host_data, shape, ndim);
+  API_END
+}
+
+int t2p_engine_finalize(t2p_engine* e) {
+  API_BEGIN
+  T2P_REQUIRE(e, "null engine");
+  return e->impl.finalize();
+  API_END
+}
+
+int t2p_engine_set_context(t2p_engine* e, const float* context, int batch, int tokens, void* stream) {
+  API_BEGIN
+  T2P_REQUIRE(e, "null engine");
+  return e->impl.set_context(context, batch, tokens, (hipStream_t)stream);
+  API_END
+}
+
+int t2p_engine_score(t2p_engine* e, const float* x, const int32_t* labels, float* out, int batch, void* stream) {
+  API_BEGIN
+  T2P_REQUIRE(e && labels, "null argument");
+  return e->impl.score(x, labels, nullptr, out, batch, (hipStream_t)stream);
+  API_END
+}
+
+int64_t t2p_engine_device_bytes(const t2p_engine* e) { return e ? e->impl.device_bytes() : 0; }
+
+int t2p_sampler_create(t2p_engine* e, const t2p_sampler_config* cfg, const float* g_table, t2p_sampler** out) {
+  API_BEGIN
+  T2P_REQUIRE(e && cfg && out, "null argument");
+  t2p_sampler* s = new t2p_sampler(&e->impl, *cfg);
+  int rc = s->impl.init(g_table);
+  if (rc != T2P_OK) {
+    delete s;
+    return rc;
+  }
+  *out = s;
+  return T2P_OK;
+  API_END
+}
+
+void t2p_sampler_destroy(t2p_sampler* s) { delete s; }
+
+int t2p_sampler_set_condition(t2p_sampler* s, const uint8_t* mask, const float* x_initial) {
+  API_BEGIN
+  T2P_REQUIRE(s, "null sampler");
+  T2P_REQUIRE((mask == nullptr) == (x_initial == nullptr), "mask and x_initial go together");
+  return s->impl.set_condition(mask, x_initial);
+  API_END
+}
+
+int t2p_sampler_reset(t2p_sampler* s, int step, void* stream) {
+  API_BEGIN
+  T2P_REQUIRE(s, "null sampler");
+  return s->impl.reset(step, (hipStream_t)stream);
+  API_END
+}
+
+int t2p_sampler_step(t2p_sampler* s, float* x, float* x_mean, const float* noise_corrector, const float* noise_predictor,
+                     void* stream) {
+  API_BEGIN
+  T2P_REQUIRE(s, "null sampler");
+  return s->impl.step(x, x_mean, noise_corrector, noise_predictor, (hipStream_t)stream);
+  API_END
+}
+
+int t2p_sampler_run(t2p_sampler* s, float* x, float* out, int prior_given, int n_steps, void* stream) {
+  API_BEGIN
+  T2P_REQUIRE(s, "null sampler");
+  return s->impl.run(x, out, prior_given, n_steps, (hipStream_t)stream);
+  API_END
+}
+
+// ---- operators ------------------------------------------------------------------------------------
+int t2p_op_gemm(int dtype, const void* A, int a_f32, const void* Bw, void* C, int c_f32, int M, int N, int K, int64_t lda,
+                int64_t ldb, int64_t ldc, const float* bias_n, const float* residual, float alpha, void* stream) {
+  API_BEGIN
+  GemmParams p;
+  p.dtype = dtype; p.A0 = A; p.a_f32 = a_f32; p.C0 = K; p.lda0 = lda; p.Bw = Bw; p.ldb = ldb; p.M = M; p.N = N;
+  p.bias_n = bias_n; p.R = residual; p.ldr = ldc; p.alpha = alpha; p.C = C; p.c_f32 = c_f32; p.ldc = ldc;
+  return launch_gemm(p, (hipStream_t)stream);
+  API_END
+}
+
+int t2p_op_conv3x3(int dtype, const void* x, int a_f32, const void* w, const float* bias, float* out, int batch, int H,
+                   int W, int Cin, int Cout, int upsample, void* stream) {
+  API_BEGIN
+  GemmParams p;
+  p.dtype = dtype; p.A0 = x; p.a_f32 = a_f32; p.C0 = Cin; p.lda0 = Cin; p.taps = 9; p.H = H; p.W = W; p.a_up = upsample;
+  p.Bw = w; p.ldb = 9L * Cin; p.M = batch * H * W; p.N = Cout; p.bias_n = bias; p.rows_per_batch = H * W;
+  p.C = out; p.c_f32 = 1; p.ldc = Cout;
+  return launch_gemm(p, (hipStream_t)stream);
+  API_END
+}
+
+int t2p_op_groupnorm(const float* x0, const float* x1, int C0, int C1, int batch, int H, int W, int groups,
+                     const float* gamma, const float* beta, float eps, int silu, int down, void* out, int dtype,
+                     void* stream) {
+  API_BEGIN
+  hipStream_t s = (hipStream_t)stream;
+  GroupNormArgs a;
+  a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.B = batch; a.HW = H * W; a.G = groups; a.eps = eps;
+  const int C = C0 + C1;
+  const int nparts = gn_num_chunks(a.HW) * ((C + 1023) / 1024);
+  float* ws = nullptr;
+  T2P_HIP_CHECK(hipMalloc((void**)&ws, ((size_t)batch * nparts * groups * 2 + (size_t)batch * groups * 2) * 4));
+  a.partial = ws;
+  a.stats = ws + (size_t)batch * nparts * groups * 2;
+  int rc = launch_gn_stats(a, s);
+  if (rc == T2P_OK) {
+    GroupNormApplyArgs g;
+    g.x0 = x0; g.x1 = x1; g.C0 = C0; g.C1 = C1; g.B = batch; g.H = H; g.W = W; g.G = groups; g.stats = a.stats;
+    g.gamma = gamma; g.beta = beta; g.silu = silu; g.down = down; g.out = out; g.dtype = dtype;
+    rc = launch_gn_apply(g, s);
+  }
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(ws);
+  return rc;
+  API_END
+}
+
+int t2p_op_layernorm(const float* x, const float* gamma, const float* beta, void* out, int dtype, int64_t rows, int C,
+                     float eps, void* stream) {
+  API_BEGIN
+  return launch_layernorm(x, gamma, beta, out, dtype, rows, C, eps, (hipStream_t)stream);
+  API_END
+}
+
+int t2p_op_softmax(const float* S, int64_t lds, void* P, int64_t ldp, int dtype, int64_t rows, int n, float scale,
+                   void* stream) {
+  API_BEGIN
+  return launch_softmax(S, lds, P, ldp, dtype, rows, n, scale, (hipStream_t)stream);
+  API_END
+}
+
+int t2p_op_geglu(const float* u, void* out, int dtype, int64_t rows, int inner, void* stream) {
+  API_BEGIN
+  return launch_geglu(u, out, dtype, rows, inner, (hipStream_t)stream);
+  API_END
+}
+
+static inline int64_t rup8(int64_t v) { return (v + 7) / 8 * 8; }
+
+int64_t t2p_op_attention_ws(int dtype, int batch, int heads, int nq, int nk) {
+  const int64_t rows = (int64_t)batch * heads * nq;
+  return rows * rup8(nk) * 4 + rows * rup8(nk) * (int64_t)dtype_size(dtype) + 512;
+}
+
+int t2p_op_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                     void* out, int batch, int heads, int nq, int nk, int d, float scale, void* workspace, void* stream) {
+  API_BEGIN
+  T2P_REQUIRE(workspace && ((uintptr_t)workspace % 256) == 0, "workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const long nkp = rup8(nk), rows = (long)batch * heads * nq;
+  float* S = (float*)workspace;
+  void* P = (char*)workspace + ((rows * nkp * 4 + 255) / 256) * 256;
+  GemmParams p;
+  p.dtype = dtype; p.a_f32 = dtype == DT_F32;
+  p.A0 = q; p.C0 = d; p.lda0 = ldq; p.M = nq; p.N = nk; p.Bw = k; p.ldb = ldk;
+  p.nz0 = batch; p.nz1 = heads;
+  p.sA_z0 = (long)nq * ldq; p.sA_z1 = d; p.sB_z0 = (long)nk * ldk; p.sB_z1 = d;
+  p.C = S; p.c_f32 = 1; p.ldc = nkp; p.sC_z0 = (long)heads * nq * nkp; p.sC_z1 = (long)nq * nkp;
+  T2P_TRY(launch_gemm(p, s));
+  T2P_TRY(launch_softmax(S, nkp, P, nkp, dtype, rows, nk, scale, s));
+  GemmParams r;
+  r.dtype = dtype; r.a_f32 = dtype == DT_F32;
+  r.A0 = P; r.C0 = nk; r.lda0 = nkp; r.M = nq; r.N = d; r.Bw = vt; r.ldb = ldvt;
+  r.nz0 = batch; r.nz1 = heads;
+  r.sA_z0 = (long)heads * nq * nkp; r.sA_z1 = (long)nq * nkp; r.sB_z0 = (long)heads * d * ldvt; r.sB_z1 = (long)d * ldvt;
+  r.C = out; r.c_f32 = 0; r.ldc = (long)heads * d; r.sC_z0 = (long)nq * heads * d; r.sC_z1 = d;
+  return launch_gemm(r, s);
+  API_END
+}
+
+int t2p_op_langevin(const float* x, const float* grad, const float* noise, const uint8_t* mask, const float* x_initial,
+                    float* x_out, float* x_mean_out, int batch, int64_t per_sample, float snr, float alpha,
+                    float* sums_out, void* stream) {
+  API_BEGIN
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = nullptr;
+  T2P_HIP_CHECK(hipMalloc((void**)&ws, ((size_t)batch * 64 * 2 + 64) * 4));
+  float* sums = sums_out ? sums_out : ws + (size_t)batch * 64 * 2;
+  int rc = launch_langevin_norms(grad, noise, batch, per_sample, ws, sums, s);
+  if (rc == T2P_OK) {
+    SdeUpdateArgs a;
+    a.x = x; a.score = grad; a.noise = noise; a.mask = mask; a.x_initial = x_initial; a.x_out = x_out;
+    a.x_mean_out = x_mean_out; a.n = per_sample * batch;
+    rc = launch_langevin_update(a, sums, (float)batch, snr, alpha, s);
+  }
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(ws);
+  return rc;
+  API_END
+}
+
+int t2p_op_predictor(const float* x, const float* score, const float* noise, const uint8_t* mask, const float* x_initial,
+                     float* x_out, float* x_mean_out, int64_t n, float G, int probability_flow, void* stream) {
+  API_BEGIN
+  SdeUpdateArgs a;
+  a.x = x; a.score = score; a.noise = noise; a.mask = mask; a.x_initial = x_initial; a.x_out = x_out;
+  a.x_mean_out = x_mean_out; a.n = n;
+  return launch_predictor_update(a, nullptr, nullptr, G, probability_flow, (hipStream_t)stream);
+  API_END
+}
+
+int t2p_op_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+  API_BEGIN
+  return launch_philox_normal(out, n, seed, stream_id, nullptr, (hipStream_t)stream);
+  API_END
+}
+
+int t2p_op_convert(const float* in, void* out, int dtype, int64_t n, void* stream) {
+  API_BEGIN
+  return launch_convert(in, out, dtype, n, (hipStream_t)stream);
+  API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,911 @@
+// Host side of the score network (reference UNetModel, ncsnpp.py:71-263) and of the
+// predictor-corrector loop (sampling.py:245-289): builds the layer table from the flat config,
+// prepares weights (layout + dtype), and enqueues the HIP kernels of one evaluation on a stream.
+// No host synchronisation happens inside score()/step(): the Langevin step size is computed on
+// the device from device-side norm sums.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace t2p {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+const char* get_last_error() { return g_last_error.c_str(); }
+
+// ------------------------------------------------------------------------------------------------
+DevPool::~DevPool() {
+  for (void* p : all_) (void)hipFree(p);
+}
+static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+void* DevPool::get(size_t bytes) {
+  bytes = round_up(std::max<size_t>(bytes, 256), 256);
+  auto it = free_.find(bytes);
+  if (it != free_.end()) {
+    void* p = it->second;
+    free_.erase(it);
+    return p;
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    set_last_error("hipMalloc of " + std::to_string(bytes) + " bytes failed");
+    return nullptr;
+  }
+  size_of_[p] = bytes;
+  all_.push_back(p);
+  held_ += bytes;
+  return p;
+}
+void DevPool::put(void* p) {
+  if (!p) return;
+  auto it = size_of_.find(p);
+  if (it != size_of_.end()) free_.emplace(it->second, p);
+}
+void* DevPool::persistent(size_t bytes) {
+  bytes = round_up(std::max<size_t>(bytes, 256), 256);
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    set_last_error("hipMalloc of " + std::to_string(bytes) + " bytes failed");
+    return nullptr;
+  }
+  all_.push_back(p);
+  held_ += bytes;
+  return p;
+}
+
+#define POOL_GET(var, type, bytes)                          \
+  type var = (type)pool_.get(bytes);                        \
+  if (!var) return T2P_ERR_HIP;
+
+// ------------------------------------------------------------------------------------------------
+static int gn_groups(int c) { return std::min(c / 4, 32); }  // layers.py:282
+
+Engine::Engine(const t2p_model_config& cfg) : cfg_(cfg) {}
+Engine::~Engine() {}
+
+static void add(std::vector<ParamInfo>& v, const std::string& n, std::vector<int64_t> s) { v.push_back({n, std::move(s)}); }
+
+static void res_params(std::vector<ParamInfo>& v, const Layer& l, int td) {
+  const std::string& p = l.prefix;
+  const int64_t ci = l.in_ch, co = l.out_ch;
+  add(v, p + ".GroupNorm_0.weight", {ci}); add(v, p + ".GroupNorm_0.bias", {ci});
+  add(v, p + ".Conv_0.weight", {co, ci, 3, 3}); add(v, p + ".Conv_0.bias", {co});
+  add(v, p + ".Dense_0.weight", {co, td}); add(v, p + ".Dense_0.bias", {co});
+  add(v, p + ".GroupNorm_1.weight", {co}); add(v, p + ".GroupNorm_1.bias", {co});
+  add(v, p + ".Conv_1.weight", {co, co, 3, 3}); add(v, p + ".Conv_1.bias", {co});
+  if (l.has_conv2) { add(v, p + ".Conv_2.weight", {co, ci, 1, 1}); add(v, p + ".Conv_2.bias", {co}); }
+}
+static void attn_params(std::vector<ParamInfo>& v, const Layer& l) {
+  const int64_t c = l.in_ch;
+  add(v, l.prefix + ".GroupNorm_0.weight", {c}); add(v, l.prefix + ".GroupNorm_0.bias", {c});
+  for (int i = 0; i < 4; ++i) {
+    add(v, l.prefix + ".NIN_" + std::to_string(i) + ".W", {c, c});
+    add(v, l.prefix + ".NIN_" + std::to_string(i) + ".b", {c});
+  }
+}
+static void st_params(std::vector<ParamInfo>& v, const Layer& l, int64_t ctx) {
+  const std::string& p = l.prefix;
+  const std::string t = p + ".transformer_blocks.0";
+  const int64_t c = l.in_ch;
+  add(v, p + ".norm.weight", {c}); add(v, p + ".norm.bias", {c});
+  add(v, p + ".proj_in.weight", {c, c, 1, 1}); add(v, p + ".proj_in.bias", {c});
+  add(v, t + ".attn1.to_q.weight", {c, c}); add(v, t + ".attn1.to_k.weight", {c, c});
+  add(v, t + ".attn1.to_v.weight", {c, c}); add(v, t + ".attn1.to_out.0.weight", {c, c});
+  add(v, t + ".attn1.to_out.0.bias", {c});
+  add(v, t + ".ff.net.0.proj.weight", {8 * c, c}); add(v, t + ".ff.net.0.proj.bias", {8 * c});
+  add(v, t + ".ff.net.2.weight", {c, 4 * c}); add(v, t + ".ff.net.2.bias", {c});
+  add(v, t + ".attn2.to_q.weight", {c, c}); add(v, t + ".attn2.to_k.weight", {c, ctx});
+  add(v, t + ".attn2.to_v.weight", {c, ctx}); add(v, t + ".attn2.to_out.0.weight", {c, c});
+  add(v, t + ".attn2.to_out.0.bias", {c});
+  for (int i = 1; i <= 3; ++i) {
+    add(v, t + ".norm" + std::to_string(i) + ".weight", {c});
+    add(v, t + ".norm" + std::to_string(i) + ".bias", {c});
+  }
+  add(v, p + ".proj_out.weight", {c, c, 1, 1}); add(v, p + ".proj_out.bias", {c});
+}
+
+int Engine::build() {
+  const t2p_model_config& c = cfg_;
+  T2P_REQUIRE(c.n_ch_mult >= 1 && c.n_ch_mult <= 8, "ch_mult length");
+  T2P_REQUIRE(c.n_attn_resolutions >= 0 && c.n_attn_resolutions <= 8, "attn_resolutions length");
+  T2P_REQUIRE(c.nf >= 8 && c.nf % 8 == 0, "nf must be a multiple of 8");
+  T2P_REQUIRE(c.num_channels >= 1 && c.num_channels <= 8, "num_channels must be in [1, 8]");
+  T2P_REQUIRE(c.max_res_num % (1 << (c.n_ch_mult - 1)) == 0, "max_res_num must be divisible by 2^(levels-1)");
+  T2P_REQUIRE(c.n_heads >= 1 && c.context_dim >= 8 && c.context_dim % 8 == 0, "n_heads / context_dim");
+  T2P_REQUIRE(c.num_scales >= 2 && c.sigma_min > 0 && c.sigma_max > c.sigma_min, "sigma schedule");
+  T2P_REQUIRE(c.compute_dtype >= 0 && c.compute_dtype <= 2, "compute_dtype");
+  nf_ = c.nf;
+  temb_dim_ = 4 * nf_;
+  cpad_ = 8;
+  const int nres = c.n_ch_mult, nrb = c.num_res_blocks, L = c.max_res_num;
+  auto in_attn = [&](int res) {
+    for (int i = 0; i < c.n_attn_resolutions; ++i)
+      if (c.attn_resolutions[i] == res) return true;
+    return false;
+  };
+  auto mk = [&](int kind, const std::string& prefix, int ci, int co, int up, int down) {
+    Layer l;
+    l.kind = kind; l.prefix = prefix; l.in_ch = ci; l.out_ch = co; l.up = up; l.down = down;
+    l.has_conv2 = (kind == 0) && (ci != co || up || down);
+    if (kind == 0) { l.temb_off = temb_total_; temb_total_ += co; }
+    return l;
+  };
+  auto attn_pair = [&](Stage& st, const std::string& prefix, int idx0, int ch) -> int {
+    T2P_REQUIRE(ch % 32 == 0 && ch % c.n_heads == 0 && (ch / c.n_heads) % 8 == 0,
+                "attention levels need channels % 32 == 0 and head dim % 8 == 0");
+    st.layers.push_back(mk(1, prefix + "." + std::to_string(idx0), ch, ch, 0, 0));
+    st.layers.push_back(mk(2, prefix + "." + std::to_string(idx0 + 1), ch, ch, 0, 0));
+    return T2P_OK;
+  };
+  std::vector<int> skip_ch{nf_};
+  int in_ch = nf_;
+  for (int lvl = 0; lvl < nres; ++lvl) {
+    const int res = L >> lvl;
+    for (int b = 0; b < nrb; ++b) {
+      const int out_ch = nf_ * c.ch_mult[lvl];
+      const std::string prefix = "input_blocks." + std::to_string(input_stages_.size());
+      Stage st;
+      st.layers.push_back(mk(0, prefix + ".0", in_ch, out_ch, 0, 0));
+      in_ch = out_ch;
+      if (in_attn(res)) T2P_TRY(attn_pair(st, prefix, 1, in_ch));
+      input_stages_.push_back(std::move(st));
+      skip_ch.push_back(in_ch);
+    }
+    if (lvl != nres - 1) {
+      const std::string prefix = "input_blocks." + std::to_string(input_stages_.size());
+      Stage st;
+      st.layers.push_back(mk(0, prefix + ".0", in_ch, in_ch, 0, 1));
+      input_stages_.push_back(std::move(st));
+      skip_ch.push_back(in_ch);
+    }
+  }
+  const int mid = skip_ch.back();
+  mid_stage_.layers.push_back(mk(0, "mid_blocks.0", mid, mid, 0, 0));
+  T2P_TRY(attn_pair(mid_stage_, "mid_blocks", 1, mid));
+  mid_stage_.layers.push_back(mk(0, "mid_blocks.3", mid, mid, 0, 0));
+  in_ch = mid;
+  for (int lvl = nres - 1; lvl >= 0; --lvl) {
+    const int res = L >> lvl;
+    for (int b = 0; b <= nrb; ++b) {
+      const int out_ch = nf_ * c.ch_mult[lvl];
+      const std::string prefix = "out_blocks." + std::to_string(out_stages_.size());
+      Stage st;
+      st.skip_ch = skip_ch.back();
+      skip_ch.pop_back();
+      st.layers.push_back(mk(0, prefix + ".0", in_ch + st.skip_ch, out_ch, 0, 0));
+      in_ch = out_ch;
+      if (in_attn(res)) T2P_TRY(attn_pair(st, prefix, 1, in_ch));
+      if (lvl != 0 && b == nrb)
+        st.layers.push_back(mk(0, prefix + "." + std::to_string(st.layers.size()), in_ch, in_ch, 1, 0));
+      out_stages_.push_back(std::move(st));
+    }
+  }
+  T2P_REQUIRE(skip_ch.empty(), "skip stack not consumed");
+  final_ch_ = in_ch;
+
+  // parameter table in reference parameters() order
+  const int64_t td = temb_dim_, nf = nf_, ch = c.num_channels;
+  add(params_, "pre_blocks.0.weight", {td, nf}); add(params_, "pre_blocks.0.bias", {td});
+  add(params_, "pre_blocks.1.weight", {td, td}); add(params_, "pre_blocks.1.bias", {td});
+  add(params_, "pre_conv.weight", {nf, ch, 3, 3}); add(params_, "pre_conv.bias", {nf});
+  auto walk = [&](Stage& st) {
+    for (Layer& l : st.layers) {
+      if (l.kind == 0) res_params(params_, l, temb_dim_);
+      else if (l.kind == 1) attn_params(params_, l);
+      else st_params(params_, l, c.context_dim);
+    }
+  };
+  for (Stage& st : input_stages_) walk(st);
+  walk(mid_stage_);
+  for (Stage& st : out_stages_) walk(st);
+  add(params_, "out.0.weight", {final_ch_}); add(params_, "out.0.bias", {final_ch_});
+  add(params_, "out.2.weight", {ch, final_ch_, 3, 3}); add(params_, "out.2.bias", {ch});
+  return T2P_OK;
+}
+
+int Engine::load_param(const char* name, const float* data, const int64_t* shape, int ndim) {
+  T2P_REQUIRE(name && data && shape && ndim >= 1 && ndim <= 4, "load_param arguments");
+  T2P_REQUIRE(!finalized_, "engine already finalized");
+  std::string n(name);
+  if (n.rfind("module.", 0) == 0) n = n.substr(7);   // DataParallel state dict (score_sde_pytorch/utils.py:8)
+  if (n == "sigmas") return T2P_OK;                   // float64 buffer: derived from the config here
+  const ParamInfo* info = nullptr;
+  for (const ParamInfo& p : params_)
+    if (p.name == n) { info = &p; break; }
+  if (!info) {   // load_state_dict(strict=False) ignores unknown keys (score_sde_pytorch/utils.py:14)
+    return T2P_OK;
+  }
+  std::vector<int64_t> s(shape, shape + ndim);
+  if (s != info->shape) {
+    set_last_error("shape mismatch for " + n);
+    return T2P_ERR_INVALID;
+  }
+  int64_t numel = 1;
+  for (int64_t d : s) numel *= d;
+  HostTensor& t = host_[n];
+  t.shape = s;
+  t.data.assign(data, data + numel);
+  return T2P_OK;
+}
+
+const HostTensor* Engine::host(const std::string& name, std::vector<int64_t> shape) {
+  auto it = host_.find(name);
+  if (it == host_.end()) {
+    set_last_error("parameter not loaded: " + name);
+    return nullptr;
+  }
+  if (it->second.shape != shape) {
+    set_last_error("unexpected shape for " + name);
+    return nullptr;
+  }
+  return &it->second;
+}
+
+int Engine::upload_f32(const std::vector<float>& v, float** out) {
+  float* d = (float*)pool_.persistent(v.size() * 4);
+  if (!d) return T2P_ERR_HIP;
+  T2P_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+  *out = d;
+  return T2P_OK;
+}
+
+static int upload_matrix(DevPool& pool, const std::vector<float>& m, int dtype, void** out) {
+  const size_t n = m.size();
+  void* d = pool.persistent(n * dtype_size(dtype));
+  if (!d) return T2P_ERR_HIP;
+  if (dtype == DT_F32) {
+    T2P_HIP_CHECK(hipMemcpy(d, m.data(), n * 4, hipMemcpyHostToDevice));
+  } else {
+    std::vector<uint16_t> h(n);
+    if (dtype == DT_BF16) {
+      for (size_t i = 0; i < n; ++i) h[i] = f32_to_bf16_bits(m[i]);
+    } else {
+      for (size_t i = 0; i < n; ++i) {
+        _Float16 x = (_Float16)m[i];
+        std::memcpy(&h[i], &x, 2);
+      }
+    }
+    T2P_HIP_CHECK(hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice));
+  }
+  *out = d;
+  return T2P_OK;
+}
+
+// [N][K] matrix in the layout the GEMM wants, from a reference tensor:
+//   Linear / 1x1 conv : (N, K[,1,1])  as is          NIN : (K, N) transposed
+//   3x3 conv          : (N, Cin, 3, 3) -> [N][kh*3+kw][Cin (padded to cin_pad)]
+static std::vector<float> to_nk(const HostTensor& t, bool conv3x3, bool nin, int cin_pad = 0) {
+  if (conv3x3) {
+    const int64_t N = t.shape[0], ci = t.shape[1];
+    const int64_t cp = cin_pad ? cin_pad : ci;
+    std::vector<float> m((size_t)N * 9 * cp, 0.f);
+    for (int64_t n = 0; n < N; ++n)
+      for (int64_t c = 0; c < ci; ++c)
+        for (int tap = 0; tap < 9; ++tap) m[(n * 9 + tap) * cp + c] = t.data[(n * ci + c) * 9 + tap];
+    return m;
+  }
+  if (nin) {
+    const int64_t K = t.shape[0], N = t.shape[1];
+    std::vector<float> m((size_t)N * K);
+    for (int64_t k = 0; k < K; ++k)
+      for (int64_t n = 0; n < N; ++n) m[n * K + k] = t.data[k * N + n];
+    return m;
+  }
+  return t.data;
+}
+
+int Engine::upload_linear(const std::string& wname, const std::string& bname, int N, int K, DevLinear* out,
+                          bool conv3x3, bool nin, int force_dtype) {
+  std::vector<int64_t> shape;
+  int cin_pad = 0;
+  if (conv3x3) {
+    const int ci = K / 9;
+    shape = {N, ci, 3, 3};
+    if (wname == "pre_conv.weight") { shape = {N, cfg_.num_channels, 3, 3}; cin_pad = cpad_; }
+  } else if (nin) {
+    shape = {K, N};
+  } else {
+    shape = {N, K};
+  }
+  const HostTensor* w = host(wname, shape);
+  if (!w && !conv3x3 && !nin) {   // 1x1 convolution weights are (N, K, 1, 1)
+    w = host(wname, {N, K, 1, 1});
+  }
+  if (!w) return T2P_ERR_STATE;
+  std::vector<float> m = to_nk(*w, conv3x3, nin, cin_pad);
+  T2P_TRY(upload_matrix(pool_, m, force_dtype >= 0 ? force_dtype : cfg_.compute_dtype, &out->w));
+  out->N = N;
+  out->K = (int)(m.size() / N);
+  out->b = nullptr;
+  if (!bname.empty()) {
+    const HostTensor* b = host(bname, {N});
+    if (!b) return T2P_ERR_STATE;
+    T2P_TRY(upload_f32(b->data, &out->b));
+  }
+  return T2P_OK;
+}
+
+int Engine::upload_stack2(const std::string& w0, const std::string& b0, const std::string& w1, const std::string& b1,
+                          int N, int K, bool nin, bool has_bias, DevLinear* out) {
+  const std::vector<int64_t> shape = nin ? std::vector<int64_t>{K, N} : std::vector<int64_t>{N, K};
+  const HostTensor* t0 = host(w0, shape);
+  const HostTensor* t1 = host(w1, shape);
+  if (!t0 || !t1) return T2P_ERR_STATE;
+  std::vector<float> m = to_nk(*t0, false, nin);
+  std::vector<float> m1 = to_nk(*t1, false, nin);
+  m.insert(m.end(), m1.begin(), m1.end());
+  T2P_TRY(upload_matrix(pool_, m, cfg_.compute_dtype, &out->w));
+  out->N = 2 * N;
+  out->K = K;
+  out->b = nullptr;
+  if (has_bias) {
+    const HostTensor* c0 = host(b0, {N});
+    const HostTensor* c1 = host(b1, {N});
+    if (!c0 || !c1) return T2P_ERR_STATE;
+    std::vector<float> b = c0->data;
+    b.insert(b.end(), c1->data.begin(), c1->data.end());
+    T2P_TRY(upload_f32(b, &out->b));
+  }
+  return T2P_OK;
+}
+
+int Engine::upload_norm(const std::string& prefix, int C, int G, DevNorm* out) {
+  const HostTensor* g = host(prefix + ".weight", {C});
+  const HostTensor* b = host(prefix + ".bias", {C});
+  if (!g || !b) return T2P_ERR_STATE;
+  T2P_TRY(upload_f32(g->data, &out->gamma));
+  T2P_TRY(upload_f32(b->data, &out->beta));
+  out->C = C;
+  out->G = G;
+  return T2P_OK;
+}
+
+int Engine::finalize() {
+  T2P_REQUIRE(!finalized_, "engine already finalized");
+  for (const ParamInfo& p : params_) {
+    if (!host_.count(p.name)) {
+      set_last_error("parameter not loaded: " + p.name);
+      return T2P_ERR_STATE;
+    }
+  }
+  const int td = temb_dim_;
+  T2P_TRY(upload_linear("pre_blocks.0.weight", "pre_blocks.0.bias", td, nf_, &pre0_, false, false, DT_F32));
+  T2P_TRY(upload_linear("pre_blocks.1.weight", "pre_blocks.1.bias", td, td, &pre1_, false, false, DT_F32));
+  T2P_TRY(upload_linear("pre_conv.weight", "pre_conv.bias", nf_, 9 * cfg_.num_channels, &pre_conv_, true, false, DT_F32));
+  std::vector<float> dw((size_t)temb_total_ * td), db(temb_total_);
+  auto each_layer = [&](auto&& fn) -> int {
+    for (Stage& st : input_stages_) for (Layer& l : st.layers) T2P_TRY(fn(l));
+    for (Layer& l : mid_stage_.layers) T2P_TRY(fn(l));
+    for (Stage& st : out_stages_) for (Layer& l : st.layers) T2P_TRY(fn(l));
+    return T2P_OK;
+  };
+  T2P_TRY(each_layer([&](Layer& l) -> int {
+    const std::string& p = l.prefix;
+    const int ci = l.in_ch, co = l.out_ch;
+    if (l.kind == 0) {
+      T2P_TRY(upload_norm(p + ".GroupNorm_0", ci, gn_groups(ci), &l.gn0));
+      T2P_TRY(upload_norm(p + ".GroupNorm_1", co, gn_groups(co), &l.gn1));
+      T2P_TRY(upload_linear(p + ".Conv_0.weight", p + ".Conv_0.bias", co, 9 * ci, &l.conv0, true));
+      T2P_TRY(upload_linear(p + ".Conv_1.weight", p + ".Conv_1.bias", co, 9 * co, &l.conv1, true));
+      if (l.has_conv2) T2P_TRY(upload_linear(p + ".Conv_2.weight", p + ".Conv_2.bias", co, ci, &l.conv2));
+      const HostTensor* w = host(p + ".Dense_0.weight", {co, td});
+      const HostTensor* b = host(p + ".Dense_0.bias", {co});
+      if (!w || !b) return T2P_ERR_STATE;
+      std::copy(w->data.begin(), w->data.end(), dw.begin() + (size_t)l.temb_off * td);
+      std::copy(b->data.begin(), b->data.end(), db.begin() + l.temb_off);
+    } else if (l.kind == 1) {
+      T2P_TRY(upload_norm(p + ".GroupNorm_0", ci, gn_groups(ci), &l.gn0));
+      T2P_TRY(upload_stack2(p + ".NIN_0.W", p + ".NIN_0.b", p + ".NIN_1.W", p + ".NIN_1.b", ci, ci, true, true, &l.qk));
+      T2P_TRY(upload_linear(p + ".NIN_2.W", p + ".NIN_2.b", ci, ci, &l.v, false, true));
+      T2P_TRY(upload_linear(p + ".NIN_3.W", p + ".NIN_3.b", ci, ci, &l.out, false, true));
+    } else {
+      const std::string t = p + ".transformer_blocks.0";
+      const int ctx = cfg_.context_dim;
+      T2P_TRY(upload_norm(p + ".norm", ci, 32, &l.gn0));
+      T2P_TRY(upload_linear(p + ".proj_in.weight", p + ".proj_in.bias", ci, ci, &l.proj_in));
+      T2P_TRY(upload_linear(p + ".proj_out.weight", p + ".proj_out.bias", ci, ci, &l.proj_out));
+      T2P_TRY(upload_stack2(t + ".attn1.to_q.weight", "", t + ".attn1.to_k.weight", "", ci, ci, false, false, &l.a1_qk));
+      T2P_TRY(upload_linear(t + ".attn1.to_v.weight", "", ci, ci, &l.a1_v));
+      T2P_TRY(upload_linear(t + ".attn1.to_out.0.weight", t + ".attn1.to_out.0.bias", ci, ci, &l.a1_out));
+      T2P_TRY(upload_linear(t + ".attn2.to_q.weight", "", ci, ci, &l.a2_q));
+      T2P_TRY(upload_linear(t + ".attn2.to_k.weight", "", ci, ctx, &l.a2_k));
+      T2P_TRY(upload_linear(t + ".attn2.to_v.weight", "", ci, ctx, &l.a2_v));
+      T2P_TRY(upload_linear(t + ".attn2.to_out.0.weight", t + ".attn2.to_out.0.bias", ci, ci, &l.a2_out));
+      T2P_TRY(upload_linear(t + ".ff.net.0.proj.weight", t + ".ff.net.0.proj.bias", 8 * ci, ci, &l.ff1));
+      T2P_TRY(upload_linear(t + ".ff.net.2.weight", t + ".ff.net.2.bias", ci, 4 * ci, &l.ff2));
+      T2P_TRY(upload_norm(t + ".norm1", ci, 1, &l.ln1));
+      T2P_TRY(upload_norm(t + ".norm2", ci, 1, &l.ln2));
+      T2P_TRY(upload_norm(t + ".norm3", ci, 1, &l.ln3));
+    }
+    return T2P_OK;
+  }));
+  void* dwp = nullptr;
+  T2P_TRY(upload_matrix(pool_, dw, DT_F32, &dwp));
+  dense_all_.w = dwp;
+  dense_all_.N = temb_total_;
+  dense_all_.K = td;
+  T2P_TRY(upload_f32(db, &dense_all_.b));
+  T2P_TRY(upload_norm("out.0", final_ch_, gn_groups(final_ch_), &head_norm_));
+  T2P_TRY(upload_linear("out.2.weight", "out.2.bias", cfg_.num_channels, 9 * final_ch_, &head_conv_, true));
+
+  // 1 / sigmas[label]: sigmas = exp(linspace(log sigma_max, log sigma_min, N)) in float64
+  // (models/utils.py:50-60); the reference divides by the float64 value (ncsnpp.py:259-261).
+  const int N = cfg_.num_scales;
+  std::vector<float> inv(N);
+  const double a = std::log(cfg_.sigma_max), b = std::log(cfg_.sigma_min);
+  for (int i = 0; i < N; ++i) {
+    const double s = std::exp(a + (b - a) * (double)i / (double)(N - 1));
+    inv[i] = (float)(1.0 / s);
+  }
+  T2P_TRY(upload_f32(inv, &inv_sigma_));
+  host_.clear();
+  finalized_ = true;
+  return T2P_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int Engine::linear(const void* a, bool a_is_f32, const DevLinear& w, long rows, void* c, bool c_f32,
+                   const float* residual, float alpha, hipStream_t s, bool use_bias) {
+  GemmParams p;
+  p.dtype = dtype();
+  p.A0 = a; p.a_f32 = a_is_f32 || p.dtype == DT_F32; p.C0 = w.K; p.lda0 = w.K;
+  p.Bw = w.w; p.ldb = w.K;
+  p.M = (int)rows; p.N = w.N;
+  p.bias_n = use_bias ? w.b : nullptr;
+  p.R = residual; p.ldr = w.N;
+  p.alpha = alpha;
+  p.C = c; p.c_f32 = c_f32; p.ldc = w.N;
+  return launch_gemm(p, s);
+}
+
+int Engine::group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps, int silu, int down, int B, void** out,
+                       hipStream_t s) {
+  const int C = x.C + (x1 ? x1->C : 0);
+  T2P_REQUIRE(C == n.C, "GroupNorm channel mismatch");
+  GroupNormArgs a;
+  a.x0 = x.p; a.x1 = x1 ? x1->p : nullptr; a.C0 = x.C; a.C1 = x1 ? x1->C : 0;
+  a.B = B; a.HW = x.H * x.W; a.G = n.G; a.eps = eps;
+  const int nparts = gn_num_chunks(a.HW) * ((C + 1023) / 1024);
+  POOL_GET(partial, float*, (size_t)B * nparts * n.G * 2 * 4);
+  POOL_GET(stats, float*, (size_t)B * n.G * 2 * 4);
+  a.partial = partial; a.stats = stats;
+  T2P_TRY(launch_gn_stats(a, s));
+  GroupNormApplyArgs g;
+  g.x0 = a.x0; g.x1 = a.x1; g.C0 = a.C0; g.C1 = a.C1; g.B = B; g.H = x.H; g.W = x.W; g.G = n.G;
+  g.stats = stats; g.gamma = n.gamma; g.beta = n.beta; g.silu = silu; g.down = down; g.dtype = dtype();
+  const size_t opix = (size_t)B * (down ? x.H / 2 : x.H) * (down ? x.W / 2 : x.W);
+  POOL_GET(o, void*, opix * C * dtype_size(dtype()));
+  g.out = o;
+  T2P_TRY(launch_gn_apply(g, s));
+  pool_.put(partial);
+  pool_.put(stats);
+  *out = o;
+  return T2P_OK;
+}
+
+// ResnetBlockBigGANpp.forward (layers.py:303-327)
+int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, hipStream_t s) {
+  const int Cin = x.C + (skip ? skip->C : 0), Cout = L.out_ch;
+  T2P_REQUIRE(Cin == L.in_ch, "res block input channels");
+  T2P_REQUIRE(!(L.down && skip), "down block with concat input");
+  const int Ho = L.up ? x.H * 2 : (L.down ? x.H / 2 : x.H), Wo = L.up ? x.W * 2 : (L.down ? x.W / 2 : x.W);
+  const long rows_out = (long)B * Ho * Wo;
+  const int dt = dtype();
+  void* a0 = nullptr;
+  T2P_TRY(group_norm(x, skip, L.gn0, 1e-6f, 1, L.down, B, &a0, s));
+  POOL_GET(h1, float*, (size_t)rows_out * Cout * 4);
+  {
+    GemmParams p;
+    p.dtype = dt; p.A0 = a0; p.a_f32 = dt == DT_F32; p.C0 = Cin; p.lda0 = Cin;
+    p.taps = 9; p.H = Ho; p.W = Wo; p.a_up = L.up;
+    p.Bw = L.conv0.w; p.ldb = L.conv0.K; p.M = (int)rows_out; p.N = Cout;
+    p.bias_n = L.conv0.b; p.bias_bn = tb_ + L.temb_off; p.ld_bn = tb_ld_; p.rows_per_batch = Ho * Wo;
+    p.C = h1; p.c_f32 = 1; p.ldc = Cout;
+    T2P_TRY(launch_gemm(p, s));
+  }
+  pool_.put(a0);
+  Act h1a{h1, Cout, Ho, Wo};
+  void* a1 = nullptr;
+  T2P_TRY(group_norm(h1a, nullptr, L.gn1, 1e-6f, 1, 0, B, &a1, s));
+  pool_.put(h1);
+  // shortcut branch
+  const float* r = x.p;
+  float* rbuf = nullptr;
+  int r_up = 0;
+  if (L.has_conv2) {
+    GemmParams p;
+    p.dtype = dt; p.a_f32 = 1;
+    float* pooled = nullptr;
+    long rrows;
+    if (L.down) {
+      pooled = (float*)pool_.get((size_t)rows_out * Cin * 4);
+      if (!pooled) return T2P_ERR_HIP;
+      T2P_TRY(launch_pool2x2(x.p, pooled, B, x.H, x.W, Cin, s));
+      p.A0 = pooled; p.C0 = Cin; p.lda0 = Cin;
+      rrows = rows_out;
+    } else {
+      p.A0 = x.p; p.C0 = x.C; p.lda0 = x.C;
+      if (skip) { p.A1 = skip->p; p.C1 = skip->C; p.lda1 = skip->C; }
+      rrows = (long)B * x.H * x.W;   // for `up` the 1x1 conv runs at the low resolution: it commutes
+      r_up = L.up;                   // with nearest up-sampling exactly
+    }
+    rbuf = (float*)pool_.get((size_t)rrows * Cout * 4);
+    if (!rbuf) return T2P_ERR_HIP;
+    p.Bw = L.conv2.w; p.ldb = L.conv2.K; p.M = (int)rrows; p.N = Cout; p.bias_n = L.conv2.b;
+    p.C = rbuf; p.c_f32 = 1; p.ldc = Cout;
+    T2P_TRY(launch_gemm(p, s));
+    pool_.put(pooled);
+    r = rbuf;
+  } else {
+    T2P_REQUIRE(!skip && Cin == Cout, "identity shortcut needs equal channels");
+  }
+  POOL_GET(o, float*, (size_t)rows_out * Cout * 4);
+  {
+    GemmParams p;
+    p.dtype = dt; p.A0 = a1; p.a_f32 = dt == DT_F32; p.C0 = Cout; p.lda0 = Cout;
+    p.taps = 9; p.H = Ho; p.W = Wo;
+    p.Bw = L.conv1.w; p.ldb = L.conv1.K; p.M = (int)rows_out; p.N = Cout;
+    p.bias_n = L.conv1.b; p.rows_per_batch = Ho * Wo;
+    p.R = r; p.ldr = Cout; p.r_up = r_up;
+    p.alpha = cfg_.skip_rescale ? 0.70710678118654752440f : 1.f;
+    p.C = o; p.c_f32 = 1; p.ldc = Cout;
+    T2P_TRY(launch_gemm(p, s));
+  }
+  pool_.put(a1);
+  pool_.put(rbuf);
+  *out = Act{o, Cout, Ho, Wo};
+  return T2P_OK;
+}
+
+// softmax(q k^T * scale) v for [B][heads]; q,k row-major with head h at column h*d; vt = v^T
+int Engine::attention(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, int B,
+                      int heads, int nq, int nk, int d, float scale, hipStream_t s) {
+  const int dt = dtype();
+  const long nkp = (long)round_up((size_t)nk, 8);
+  const long rows = (long)B * heads * nq;
+  POOL_GET(S, float*, (size_t)rows * nkp * 4);
+  POOL_GET(P, void*, (size_t)rows * nkp * dtype_size(dt));
+  GemmParams p;
+  p.dtype = dt; p.a_f32 = dt == DT_F32;
+  p.A0 = q; p.C0 = d; p.lda0 = ldq; p.M = nq; p.N = nk;
+  p.Bw = k; p.ldb = ldk;
+  p.nz0 = B; p.nz1 = heads;
+  p.sA_z0 = (long)nq * ldq; p.sA_z1 = d; p.sB_z0 = (long)nk * ldk; p.sB_z1 = d;
+  p.C = S; p.c_f32 = 1; p.ldc = nkp; p.sC_z0 = (long)heads * nq * nkp; p.sC_z1 = (long)nq * nkp;
+  T2P_TRY(launch_gemm(p, s));
+  T2P_TRY(launch_softmax(S, nkp, P, nkp, dt, rows, nk, scale, s));
+  GemmParams r;
+  r.dtype = dt; r.a_f32 = dt == DT_F32;
+  r.A0 = P; r.C0 = nk; r.lda0 = nkp; r.M = nq; r.N = d;
+  r.Bw = vt; r.ldb = ldvt;
+  r.nz0 = B; r.nz1 = heads;
+  r.sA_z0 = (long)heads * nq * nkp; r.sA_z1 = (long)nq * nkp; r.sB_z0 = (long)heads * d * ldvt; r.sB_z1 = (long)d * ldvt;
+  r.C = out; r.c_f32 = 0; r.ldc = (long)heads * d; r.sC_z0 = (long)nq * heads * d; r.sC_z1 = d;
+  T2P_TRY(launch_gemm(r, s));
+  pool_.put(S);
+  pool_.put(P);
+  return T2P_OK;
+}
+
+// v^T[b] = W_v a_b^T : [C][n] (row stride npad) -- the projection is written transposed so that
+// P V is a plain "A row-major, B = [N][K]" GEMM with no transposing loads.
+static int project_vt(int dt, const DevLinear& wv, const void* a, long lda, int B, int n, long npad, void* vt,
+                      hipStream_t s) {
+  GemmParams p;
+  p.dtype = dt; p.a_f32 = dt == DT_F32;
+  p.A0 = wv.w; p.C0 = wv.K; p.lda0 = wv.K; p.M = wv.N; p.N = n;
+  p.Bw = a; p.ldb = lda;
+  p.nz0 = B; p.sA_z0 = 0; p.sB_z0 = (long)n * lda;
+  p.bias_m = wv.b;
+  p.C = vt; p.c_f32 = 0; p.ldc = npad; p.sC_z0 = (long)wv.N * npad;
+  return launch_gemm(p, s);
+}
+
+// AttnBlockpp.forward (layers.py:160-176)
+int Engine::attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
+  const int C = x.C, n = x.H * x.W, dt = dtype();
+  const size_t es = dtype_size(dt);
+  const long rows = (long)B * n, npad = (long)round_up((size_t)n, 8);
+  void* a = nullptr;
+  T2P_TRY(group_norm(x, nullptr, L.gn0, 1e-6f, 0, 0, B, &a, s));
+  POOL_GET(qk, char*, (size_t)rows * 2 * C * es);
+  T2P_TRY(linear(a, false, L.qk, rows, qk, false, nullptr, 1.f, s));
+  POOL_GET(vt, void*, (size_t)B * C * npad * es);
+  T2P_TRY(project_vt(dt, L.v, a, C, B, n, npad, vt, s));
+  pool_.put(a);
+  POOL_GET(o, void*, (size_t)rows * C * es);
+  T2P_TRY(attention(qk, 2 * C, qk + (size_t)C * es, 2 * C, vt, npad, o, B, 1, n, n, C, 1.f / std::sqrt((float)C), s));
+  pool_.put(qk);
+  pool_.put(vt);
+  POOL_GET(y, float*, (size_t)rows * C * 4);
+  T2P_TRY(linear(o, false, L.out, rows, y, true, x.p, cfg_.skip_rescale ? 0.70710678118654752440f : 1.f, s));
+  pool_.put(o);
+  *out = Act{y, C, x.H, x.W};
+  return T2P_OK;
+}
+
+// SpatialTransformer.forward with one BasicTransformerBlock (attention.py:208-215, 250-263)
+int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
+  const int C = x.C, n = x.H * x.W, dt = dtype(), heads = cfg_.n_heads, d = C / heads;
+  const size_t es = dtype_size(dt);
+  const long rows = (long)B * n, npad = (long)round_up((size_t)n, 8);
+  const float scale = 1.f / std::sqrt((float)d);
+  T2P_REQUIRE(L.ctx_k && L.ctx_vt && ctx_B_ == B, "set_context must be called with the same batch before score");
+  void* a = nullptr;
+  T2P_TRY(group_norm(x, nullptr, L.gn0, 1e-6f, 0, 0, B, &a, s));
+  POOL_GET(t, float*, (size_t)rows * C * 4);
+  T2P_TRY(linear(a, false, L.proj_in, rows, t, true, nullptr, 1.f, s));
+  pool_.put(a);
+  POOL_GET(ln, void*, (size_t)rows * C * es);
+  POOL_GET(o, void*, (size_t)rows * C * es);
+  // attn1: self-attention
+  T2P_TRY(launch_layernorm(t, L.ln1.gamma, L.ln1.beta, ln, dt, rows, C, 1e-5f, s));
+  {
+    POOL_GET(qk, char*, (size_t)rows * 2 * C * es);
+    T2P_TRY(linear(ln, false, L.a1_qk, rows, qk, false, nullptr, 1.f, s, false));
+    POOL_GET(vt, void*, (size_t)B * C * npad * es);
+    T2P_TRY(project_vt(dt, L.a1_v, ln, C, B, n, npad, vt, s));
+    T2P_TRY(attention(qk, 2 * C, qk + (size_t)C * es, 2 * C, vt, npad, o, B, heads, n, n, d, scale, s));
+    pool_.put(qk);
+    pool_.put(vt);
+  }
+  T2P_TRY(linear(o, false, L.a1_out, rows, t, true, t, 1.f, s));
+  // attn2: cross-attention to the cached text keys / values
+  T2P_TRY(launch_layernorm(t, L.ln2.gamma, L.ln2.beta, ln, dt, rows, C, 1e-5f, s));
+  {
+    POOL_GET(q, void*, (size_t)rows * C * es);
+    T2P_TRY(linear(ln, false, L.a2_q, rows, q, false, nullptr, 1.f, s, false));
+    T2P_TRY(attention(q, C, L.ctx_k, C, L.ctx_vt, ctx_Tpad_, o, B, heads, n, ctx_T_, d, scale, s));
+    pool_.put(q);
+  }
+  T2P_TRY(linear(o, false, L.a2_out, rows, t, true, t, 1.f, s));
+  // feed-forward with GEGLU
+  T2P_TRY(launch_layernorm(t, L.ln3.gamma, L.ln3.beta, ln, dt, rows, C, 1e-5f, s));
+  {
+    POOL_GET(u, float*, (size_t)rows * 8 * C * 4);
+    T2P_TRY(linear(ln, false, L.ff1, rows, u, true, nullptr, 1.f, s));
+    POOL_GET(g, void*, (size_t)rows * 4 * C * es);
+    T2P_TRY(launch_geglu(u, g, dt, rows, 4 * C, s));
+    pool_.put(u);
+    T2P_TRY(linear(g, false, L.ff2, rows, t, true, t, 1.f, s));
+    pool_.put(g);
+  }
+  pool_.put(ln);
+  pool_.put(o);
+  POOL_GET(y, float*, (size_t)rows * C * 4);
+  T2P_TRY(linear(t, true, L.proj_out, rows, y, true, x.p, 1.f, s));
+  pool_.put(t);
+  *out = Act{y, C, x.H, x.W};
+  return T2P_OK;
+}
+
+int Engine::run_stage(Stage& st, Act& h, const Act* skip, int B, hipStream_t s) {
+  Act cur = h;
+  bool own = false;   // cur was produced inside this stage
+  for (size_t i = 0; i < st.layers.size(); ++i) {
+    Layer& L = st.layers[i];
+    Act nxt;
+    if (L.kind == 0) T2P_TRY(res_block(L, cur, i == 0 ? skip : nullptr, &nxt, B, s));
+    else if (L.kind == 1) T2P_TRY(attn_block(L, cur, &nxt, B, s));
+    else T2P_TRY(st_block(L, cur, &nxt, B, s));
+    if (own) pool_.put(cur.p);
+    cur = nxt;
+    own = true;
+  }
+  h = cur;
+  return T2P_OK;
+}
+
+int Engine::set_context(const float* ctx, int B, int T, hipStream_t s) {
+  T2P_REQUIRE(finalized_, "finalize the engine first");
+  T2P_REQUIRE(ctx && B > 0 && T > 0, "set_context arguments");
+  const int dt = dtype(), D = cfg_.context_dim;
+  const size_t es = dtype_size(dt);
+  const long Tpad = (long)round_up((size_t)T, 8);
+  const bool realloc = (B != ctx_B_ || T != ctx_T_);
+  const void* cx = ctx;
+  void* conv = nullptr;
+  if (dt != DT_F32) {
+    conv = pool_.get((size_t)B * T * D * es);
+    if (!conv) return T2P_ERR_HIP;
+    T2P_TRY(launch_convert(ctx, conv, dt, (long)B * T * D, s));
+    cx = conv;
+  }
+  auto each = [&](Layer& l) -> int {
+    if (l.kind != 2) return T2P_OK;
+    const int C = l.in_ch;
+    if (realloc || !l.ctx_k) {
+      pool_.put(l.ctx_k);
+      pool_.put(l.ctx_vt);
+      l.ctx_k = pool_.get((size_t)B * T * C * es);
+      l.ctx_vt = pool_.get((size_t)B * C * Tpad * es);
+      if (!l.ctx_k || !l.ctx_vt) return T2P_ERR_HIP;
+    }
+    T2P_TRY(linear(cx, false, l.a2_k, (long)B * T, l.ctx_k, false, nullptr, 1.f, s, false));
+    T2P_TRY(project_vt(dt, l.a2_v, cx, D, B, T, Tpad, l.ctx_vt, s));
+    return T2P_OK;
+  };
+  for (Stage& st : input_stages_) for (Layer& l : st.layers) T2P_TRY(each(l));
+  for (Layer& l : mid_stage_.layers) T2P_TRY(each(l));
+  for (Stage& st : out_stages_) for (Layer& l : st.layers) T2P_TRY(each(l));
+  pool_.put(conv);
+  ctx_B_ = B; ctx_T_ = T; ctx_Tpad_ = (int)Tpad;
+  return T2P_OK;
+}
+
+// UNetModel.forward (ncsnpp.py:220-263)
+int Engine::score(const float* x, const int* labels, const int* step_counter, float* out, int B, hipStream_t s) {
+  T2P_REQUIRE(finalized_, "finalize the engine first");
+  T2P_REQUIRE(x && out && B > 0 && (labels || step_counter), "score arguments");
+  const int L = cfg_.max_res_num, HW = L * L, Cx = cfg_.num_channels, N = cfg_.num_scales;
+  const int R = labels ? B : 1;
+  POOL_GET(emb, float*, (size_t)R * nf_ * 4);
+  POOL_GET(t1, float*, (size_t)R * temb_dim_ * 4);
+  POOL_GET(t2, float*, (size_t)R * temb_dim_ * 4);
+  POOL_GET(tb, float*, (size_t)R * temb_total_ * 4);
+  T2P_TRY(launch_timestep_embedding(labels, step_counter, emb, R, nf_, s));
+  T2P_TRY(launch_small_linear(emb, (const float*)pre0_.w, pre0_.b, t1, R, nf_, temb_dim_, 0, s));
+  T2P_TRY(launch_small_linear(t1, (const float*)pre1_.w, pre1_.b, t2, R, temb_dim_, temb_dim_, 0, s));
+  T2P_TRY(launch_small_linear(t2, (const float*)dense_all_.w, dense_all_.b, tb, R, temb_dim_, temb_total_, 1, s));
+  tb_ = tb;
+  tb_ld_ = labels ? temb_total_ : 0;
+  POOL_GET(scale, float*, (size_t)B * 4);
+  if (cfg_.scale_by_sigma) {
+    T2P_TRY(launch_gather_label(labels, step_counter, inv_sigma_, scale, B, N, s));
+  } else {
+    std::vector<float> ones(B, 1.f);
+    T2P_HIP_CHECK(hipMemcpyAsync(scale, ones.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
+    T2P_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  POOL_GET(xin, float*, (size_t)B * HW * cpad_ * 4);
+  T2P_TRY(launch_nchw_to_nhwc(x, xin, B, Cx, HW, cpad_, s));
+  POOL_GET(h0, float*, (size_t)B * HW * nf_ * 4);
+  {
+    GemmParams p;   // pre_conv always in exact fp32: the input has the dynamic range of sigma_max
+    p.dtype = DT_F32; p.a_f32 = 1; p.A0 = xin; p.C0 = cpad_; p.lda0 = cpad_;
+    p.taps = 9; p.H = L; p.W = L;
+    p.Bw = pre_conv_.w; p.ldb = pre_conv_.K; p.M = B * HW; p.N = nf_; p.bias_n = pre_conv_.b;
+    p.rows_per_batch = HW;
+    p.C = h0; p.c_f32 = 1; p.ldc = nf_;
+    T2P_TRY(launch_gemm(p, s));
+  }
+  pool_.put(xin);
+  pool_.put(emb); pool_.put(t1); pool_.put(t2);
+
+  std::vector<Act> hs;
+  Act h{h0, nf_, L, L};
+  hs.push_back(h);
+  for (Stage& st : input_stages_) {
+    T2P_TRY(run_stage(st, h, nullptr, B, s));
+    hs.push_back(h);
+  }
+  // mid stage: its input stays on the skip stack
+  T2P_TRY(run_stage(mid_stage_, h, nullptr, B, s));
+  for (Stage& st : out_stages_) {
+    Act skip = hs.back();
+    hs.pop_back();
+    T2P_REQUIRE(skip.C == st.skip_ch && skip.H == h.H, "skip stack mismatch");
+    Act in = h;
+    T2P_TRY(run_stage(st, h, &skip, B, s));
+    pool_.put(in.p);
+    pool_.put(skip.p);
+  }
+  T2P_REQUIRE(hs.empty(), "skip stack not consumed");
+  // head: GroupNorm -> SiLU -> conv3x3 (nf -> C), stored NCHW and divided by sigma[label]
+  void* a = nullptr;
+  T2P_TRY(group_norm(h, nullptr, head_norm_, 1e-6f, 1, 0, B, &a, s));
+  pool_.put(h.p);
+  {
+    GemmParams p;
+    p.dtype = dtype(); p.a_f32 = p.dtype == DT_F32; p.A0 = a; p.C0 = final_ch_; p.lda0 = final_ch_;
+    p.taps = 9; p.H = L; p.W = L;
+    p.Bw = head_conv_.w; p.ldb = head_conv_.K; p.M = B * HW; p.N = Cx; p.bias_n = head_conv_.b;
+    p.rows_per_batch = HW;
+    p.C = out; p.c_f32 = 1; p.c_nchw = 1; p.row_scale = scale;
+    T2P_TRY(launch_gemm(p, s));
+  }
+  pool_.put(a);
+  pool_.put(scale);
+  pool_.put(tb);
+  tb_ = nullptr;
+  return T2P_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+Sampler::Sampler(Engine* e, const t2p_sampler_config& cfg) : e_(e), cfg_(cfg) {}
+
+int Sampler::init(const float* g_table_host) {
+  T2P_REQUIRE(cfg_.sde == T2P_SDE_VE, "the fused sampler covers the VE SDE (every shipped config); VP runs through the operator API");
+  T2P_REQUIRE(cfg_.N == e_->cfg().num_scales, "sde.N must equal model.num_scales");
+  T2P_REQUIRE(cfg_.batch > 0 && cfg_.global_batch >= cfg_.batch && cfg_.n_steps_each >= 1, "sampler config");
+  const int N = cfg_.N;
+  std::vector<float> g(N);
+  if (g_table_host) {
+    std::copy(g_table_host, g_table_host + N, g.begin());
+  } else {
+    // VESDE.discretize (sde_lib.py:237-245): step i uses k = N-1-i on the ascending sigmas
+    const double a = std::log(cfg_.sigma_min), b = std::log(cfg_.sigma_max);
+    auto sig = [&](int k) { return (double)(float)std::exp(a + (b - a) * (double)k / (double)(N - 1)); };
+    for (int i = 0; i < N; ++i) {
+      const int k = N - 1 - i;
+      const double sk = sig(k), sp = k == 0 ? 0.0 : sig(k - 1);
+      g[i] = (float)std::sqrt(sk * sk - sp * sp);
+    }
+  }
+  DevPool& pool = e_->pool();
+  g_table_ = (float*)pool.persistent((size_t)N * 4);
+  step_dev_ = (int*)pool.persistent(256);
+  const t2p_model_config& m = e_->cfg();
+  per_sample_ = (long)m.num_channels * m.max_res_num * m.max_res_num;
+  n_ = per_sample_ * cfg_.batch;
+  score_ = (float*)pool.persistent((size_t)n_ * 4);
+  noise_ = (float*)pool.persistent((size_t)n_ * 4);
+  xmean_ = (float*)pool.persistent((size_t)n_ * 4);
+  sq_ws_ = (float*)pool.persistent((size_t)cfg_.batch * 64 * 2 * 4);
+  sums_ = (float*)pool.persistent(256);
+  if (!g_table_ || !step_dev_ || !score_ || !noise_ || !xmean_ || !sq_ws_ || !sums_) return T2P_ERR_HIP;
+  T2P_HIP_CHECK(hipMemcpy(g_table_, g.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+  T2P_HIP_CHECK(hipMemset(step_dev_, 0, 256));
+  return T2P_OK;
+}
+
+int Sampler::reset(int step, hipStream_t s) {
+  T2P_REQUIRE(step >= 0 && step < cfg_.N, "step out of range");
+  T2P_HIP_CHECK(hipMemcpyAsync(step_dev_, &step, sizeof(int), hipMemcpyHostToDevice, s));
+  T2P_HIP_CHECK(hipStreamSynchronize(s));
+  return T2P_OK;
+}
+
+// one iteration of the loop body of pc_sampler (sampling.py:279-285)
+int Sampler::step(float* x, float* x_mean, const float* nc, const float* np, hipStream_t s) {
+  T2P_REQUIRE(x, "x is null");
+  T2P_REQUIRE(cfg_.n_steps_each == 1 || !nc, "injected corrector noise supports n_steps_each == 1");
+  const int B = cfg_.batch;
+  for (int k = 0; k < cfg_.n_steps_each; ++k) {
+    T2P_TRY(e_->score(x, nullptr, step_dev_, score_, B, s));
+    const float* z = nc;
+    if (!z) {
+      T2P_TRY(launch_philox_normal(noise_, n_, cfg_.seed, 2ull * k + 2, step_dev_, s));
+      z = noise_;
+    }
+    T2P_TRY(launch_langevin_norms(score_, z, B, per_sample_, sq_ws_, sums_, s));
+    SdeUpdateArgs a;
+    a.x = x; a.score = score_; a.noise = z; a.mask = mask_; a.x_initial = x_init_; a.x_out = x; a.n = n_;
+    // batch-mean norms over this process's chains; callers wanting global-batch semantics
+    // all-reduce sums_ themselves through the operator API (SURVEY 8(e) option B)
+    T2P_TRY(launch_langevin_update(a, sums_, (float)B, (float)cfg_.snr, 1.f, s));
+  }
+  T2P_TRY(e_->score(x, nullptr, step_dev_, score_, B, s));
+  const float* z = np;
+  if (!z) {
+    T2P_TRY(launch_philox_normal(noise_, n_, cfg_.seed, 1, step_dev_, s));
+    z = noise_;
+  }
+  SdeUpdateArgs a;
+  a.x = x; a.score = score_; a.noise = z; a.mask = mask_; a.x_initial = x_init_; a.x_out = x;
+  a.x_mean_out = x_mean ? x_mean : xmean_; a.n = n_;
+  T2P_TRY(launch_predictor_update(a, g_table_, step_dev_, 0.f, cfg_.probability_flow, s));
+  T2P_TRY(launch_add_int(step_dev_, 1, s));
+  return T2P_OK;
+}
+
+int Sampler::run(float* x, float* out, int prior_given, int n_steps, hipStream_t s) {
+  T2P_REQUIRE(x && out, "null pointer");
+  if (n_steps <= 0 || n_steps > cfg_.N) n_steps = cfg_.N;
+  T2P_TRY(reset(0, s));
+  if (!prior_given) {
+    // VESDE.prior_sampling (sde_lib.py:229-230) then where(mask, x, x_initial)
+    T2P_TRY(launch_philox_normal(x, n_, cfg_.seed, 0, nullptr, s));
+    T2P_TRY(launch_scale(x, n_, (float)cfg_.sigma_max, s));
+    if (mask_) T2P_TRY(launch_apply_mask(x, mask_, x_init_, n_, s));
+  }
+  for (int i = 0; i < n_steps; ++i) T2P_TRY(step(x, xmean_, nullptr, nullptr, s));
+  const float* src = cfg_.denoise ? xmean_ : x;
+  T2P_HIP_CHECK(hipMemcpyAsync(out, src, (size_t)n_ * 4, hipMemcpyDeviceToDevice, s));
+  if (cfg_.denoise && mask_) T2P_TRY(launch_apply_mask(out, mask_, x_init_, n_, s));   // sampling.py:287
+  return T2P_OK;
+}
+
+}  // namespace t2p

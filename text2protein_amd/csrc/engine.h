@@ -1,0 +1,161 @@
+// Score-network engine and predictor-corrector sampler (host side, drives the HIP kernels).
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/t2p.h"
+#include "t2p_kernels.h"
+
+namespace t2p {
+
+// Caching device allocator: exact-size free lists.  The sequence of requests of one forward pass
+// is the same every evaluation, so after the first pass no hipMalloc happens (graph-capture safe).
+class DevPool {
+ public:
+  ~DevPool();
+  void* get(size_t bytes);
+  void put(void* p);
+  size_t held_bytes() const { return held_; }
+  void* persistent(size_t bytes);  // never returned to the free lists (weights, tables)
+ private:
+  std::multimap<size_t, void*> free_;
+  std::unordered_map<void*, size_t> size_of_;
+  std::vector<void*> all_;
+  size_t held_ = 0;
+};
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct ParamInfo {
+  std::string name;
+  std::vector<int64_t> shape;
+};
+
+struct DevLinear {      // weights [N][K] in compute dtype (+ fp32 bias)
+  void* w = nullptr;
+  float* b = nullptr;
+  int N = 0, K = 0;     // K = taps * Cin for convolutions
+};
+struct DevNorm {
+  float* gamma = nullptr;
+  float* beta = nullptr;
+  int C = 0, G = 0;
+};
+
+struct Layer {
+  int kind = 0;  // 0 res, 1 attn, 2 st
+  std::string prefix;
+  int in_ch = 0, out_ch = 0, up = 0, down = 0;
+  // res
+  DevNorm gn0, gn1;
+  DevLinear conv0, conv1, conv2;
+  bool has_conv2 = false;
+  int temb_off = 0;
+  // attn (AttnBlockpp): NIN_0|NIN_1 stacked, NIN_2, NIN_3
+  DevLinear qk, v, out;
+  // st (SpatialTransformer)
+  DevLinear proj_in, proj_out, a1_qk, a1_v, a1_out, a2_q, a2_k, a2_v, a2_out, ff1, ff2;
+  DevNorm ln1, ln2, ln3;
+  void* ctx_k = nullptr;   // [B][T][C]      compute dtype (set_context)
+  void* ctx_vt = nullptr;  // [B][C][Tpad]   compute dtype
+};
+
+struct Stage {
+  std::vector<Layer> layers;
+  int skip_ch = 0;
+};
+
+struct Act {  // an NHWC fp32 activation
+  float* p = nullptr;
+  int C = 0, H = 0, W = 0;
+};
+
+class Engine {
+ public:
+  explicit Engine(const t2p_model_config& cfg);
+  ~Engine();
+  int build();  // structure + parameter table
+  const std::vector<ParamInfo>& params() const { return params_; }
+  int load_param(const char* name, const float* data, const int64_t* shape, int ndim);
+  int finalize();
+  int set_context(const float* ctx, int B, int T, hipStream_t s);
+  // labels == nullptr: every row uses *step_counter (device int)
+  int score(const float* x, const int* labels, const int* step_counter, float* out, int B, hipStream_t s);
+  int64_t device_bytes() const { return (int64_t)pool_.held_bytes(); }
+  const t2p_model_config& cfg() const { return cfg_; }
+  DevPool& pool() { return pool_; }
+  int dtype() const { return cfg_.compute_dtype; }
+
+ private:
+  int upload_linear(const std::string& wname, const std::string& bname, int N, int K, DevLinear* out,
+                    bool conv3x3 = false, bool nin = false, int force_dtype = -1);
+  int upload_stack2(const std::string& w0, const std::string& b0, const std::string& w1, const std::string& b1,
+                    int N, int K, bool nin, bool has_bias, DevLinear* out);
+  int upload_norm(const std::string& prefix, int C, int G, DevNorm* out);
+  int upload_f32(const std::vector<float>& v, float** out);
+  const HostTensor* host(const std::string& name, std::vector<int64_t> shape);
+
+  int run_stage(Stage& st, Act& h, const Act* skip, int B, hipStream_t s);
+  int res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, hipStream_t s);
+  int attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s);
+  int st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s);
+  int group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps, int silu, int down, int B, void** out,
+                 hipStream_t s);
+  int attention(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, int B,
+                int heads, int nq, int nk, int d, float scale, hipStream_t s);
+  int linear(const void* a, bool a_is_f32, const DevLinear& w, long rows, void* c, bool c_f32, const float* residual,
+             float alpha, hipStream_t s, bool use_bias = true);
+
+  t2p_model_config cfg_;
+  std::vector<ParamInfo> params_;
+  std::unordered_map<std::string, HostTensor> host_;
+  bool finalized_ = false;
+  DevPool pool_;
+
+  int nf_ = 0, temb_dim_ = 0, cpad_ = 0, final_ch_ = 0;
+  std::vector<Stage> input_stages_, out_stages_;
+  Stage mid_stage_;
+  DevLinear pre0_, pre1_, pre_conv_, head_conv_, dense_all_;
+  DevNorm head_norm_;
+  int temb_total_ = 0;
+  float* inv_sigma_ = nullptr;  // [N] fp32, 1 / sigmas[label] (descending sigmas)
+  int ctx_B_ = 0, ctx_T_ = 0, ctx_Tpad_ = 0;
+  const float* tb_ = nullptr;   // per-eval temb biases [R][temb_total_]
+  long tb_ld_ = 0;
+  friend class Sampler;
+};
+
+class Sampler {
+ public:
+  Sampler(Engine* e, const t2p_sampler_config& cfg);
+  int init(const float* g_table_host);
+  int set_condition(const uint8_t* mask, const float* x_initial) { mask_ = mask; x_init_ = x_initial; return T2P_OK; }
+  int reset(int step, hipStream_t s);
+  int step(float* x, float* x_mean, const float* nc, const float* np, hipStream_t s);
+  int run(float* x, float* out, int prior_given, int n_steps, hipStream_t s);
+
+ private:
+  Engine* e_;
+  t2p_sampler_config cfg_;
+  const uint8_t* mask_ = nullptr;
+  const float* x_init_ = nullptr;
+  int* step_dev_ = nullptr;
+  float* g_table_ = nullptr;
+  float* score_ = nullptr;
+  float* noise_ = nullptr;
+  float* sq_ws_ = nullptr;
+  float* sums_ = nullptr;
+  float* xmean_ = nullptr;
+  long n_ = 0, per_sample_ = 0;
+};
+
+}  // namespace t2p
+
+struct t2p_engine { t2p::Engine impl; explicit t2p_engine(const t2p_model_config& c) : impl(c) {} };
+struct t2p_sampler { t2p::Sampler impl; t2p_sampler(t2p::Engine* e, const t2p_sampler_config& c) : impl(e, c) {} };

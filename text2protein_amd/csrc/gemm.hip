@@ -1,0 +1,331 @@
+// MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (see GemmParams in t2p_common.h).
+//
+// Replaces, on the sampling path of the reference: nn.Conv2d 3x3 (layers.py:89-95), 1x1
+// convolutions (layers.py:82-87, attention.py:233-248), NIN (layers.py:128-137), nn.Linear
+// (attention.py:161-168, 40, 60) and the four einsum contractions of the attention blocks
+// (layers.py:166-171, attention.py:181,191).
+//
+// Structure: one workgroup = 4 wavefronts (64 lanes each) computes a BM x BN tile; wave (wm, wn)
+// owns a (BM/2) x (BN/2) sub-tile made of 32x32 MFMA tiles.  Operand tiles are staged
+// global -> registers -> LDS (16-byte vectors, 144-byte padded rows so that ds_read_b128
+// fragment reads and ds_write_b128 staging writes are bank-conflict free), double-buffered so
+// the global loads of K-tile t+1 are in flight while the MFMAs of tile t run.
+//   * fp32 compute : v_mfma_f32_32x32x2_f32  (exact f32, 64 FLOP/clk/SIMD)
+//   * bf16 / fp16  : v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulate
+// LDS rows hold BK = 128 bytes of K (32 fp32 / 64 16-bit elements); a lane's fragment for
+// k-group s is the 16 bytes at [row][32 s + 16 (lane >> 5)], for both element widths.
+#include "t2p_common.h"
+
+namespace t2p {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+static constexpr int ROWB = 144;  // LDS row stride in bytes: 128 data + 16 pad
+
+template <typename TC> struct VecInfo { static constexpr int VEC = 16 / (int)sizeof(TC); };
+
+// pack VEC floats into 16 bytes of TC
+template <typename TC> __device__ inline uint4 pack16(const float* f);
+template <> __device__ inline uint4 pack16<float>(const float* f) {
+  uint4 r;
+  r.x = __builtin_bit_cast(uint32_t, f[0]); r.y = __builtin_bit_cast(uint32_t, f[1]);
+  r.z = __builtin_bit_cast(uint32_t, f[2]); r.w = __builtin_bit_cast(uint32_t, f[3]);
+  return r;
+}
+template <> __device__ inline uint4 pack16<bf16_t>(const float* f) {
+  uint4 r;
+  r.x = (uint32_t)f32_to_bf16_bits(f[0]) | ((uint32_t)f32_to_bf16_bits(f[1]) << 16);
+  r.y = (uint32_t)f32_to_bf16_bits(f[2]) | ((uint32_t)f32_to_bf16_bits(f[3]) << 16);
+  r.z = (uint32_t)f32_to_bf16_bits(f[4]) | ((uint32_t)f32_to_bf16_bits(f[5]) << 16);
+  r.w = (uint32_t)f32_to_bf16_bits(f[6]) | ((uint32_t)f32_to_bf16_bits(f[7]) << 16);
+  return r;
+}
+template <> __device__ inline uint4 pack16<f16_t>(const float* f) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  uint4 r;
+  h2 a = {(_Float16)f[0], (_Float16)f[1]}, b = {(_Float16)f[2], (_Float16)f[3]};
+  h2 c = {(_Float16)f[4], (_Float16)f[5]}, d = {(_Float16)f[6], (_Float16)f[7]};
+  r.x = __builtin_bit_cast(uint32_t, a); r.y = __builtin_bit_cast(uint32_t, b);
+  r.z = __builtin_bit_cast(uint32_t, c); r.w = __builtin_bit_cast(uint32_t, d);
+  return r;
+}
+
+// zero the elements >= nvalid of a packed vector
+template <typename TC> __device__ inline uint4 mask_tail(uint4 v, int nvalid) {
+  constexpr int VEC = VecInfo<TC>::VEC;
+  union { uint4 u; TC e[VEC]; } x;
+  x.u = v;
+#pragma unroll
+  for (int i = 0; i < VEC; ++i)
+    if (i >= nvalid) x.e[i] = from_f32<TC>(0.f);
+  return x.u;
+}
+
+// load one staging vector (VEC K-elements) from a source row; `off` in elements
+template <typename TC, bool SRC_F32>
+__device__ inline uint4 load_vec(const void* base, long off) {
+  constexpr int VEC = VecInfo<TC>::VEC;
+  if constexpr (SRC_F32) {
+    const float* p = (const float*)base + off;
+    float f[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i += 4) {
+      float4 t = *(const float4*)(p + i);
+      f[i] = t.x; f[i + 1] = t.y; f[i + 2] = t.z; f[i + 3] = t.w;
+    }
+    return pack16<TC>(f);
+  } else {
+    return *(const uint4*)((const TC*)base + off);
+  }
+}
+
+template <typename TC> struct Mma;
+template <> struct Mma<float> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<bf16_t> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<f16_t> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+template <typename TC, bool AF32, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  constexpr int VEC = VecInfo<TC>::VEC;
+  constexpr int BK = 8 * VEC;
+  constexpr int AR = BM / 32, BR = BN / 32;  // staging rows per thread
+  constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* As = smem;                          // [2][BM][ROWB]
+  unsigned char* Bs = smem + 2 * BM * ROWB;          // [2][BN][ROWB]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+  const int z0 = blockIdx.z / p.nz1, z1 = blockIdx.z % p.nz1;
+
+  const int Ctot = p.C0 + p.C1;
+  const int nch = (Ctot + BK - 1) / BK;
+  const int nk = nch * p.taps;
+  const bool spatial = (p.taps == 9) || p.a_up;
+  const int HW = p.H * p.W;
+  const int Hs = p.a_up ? (p.H >> 1) : p.H, Ws = p.a_up ? (p.W >> 1) : p.W;
+
+  const long aoff = (long)z0 * p.sA_z0 + (long)z1 * p.sA_z1;
+  const char* A0 = (const char*)p.A0 + aoff * (AF32 ? 4 : (long)sizeof(TC));
+  const char* A1 = (const char*)p.A1;
+  const TC* Bw = (const TC*)p.Bw + (long)z0 * p.sB_z0 + (long)z1 * p.sB_z1;
+
+  // staging assignment: vector column cv (16 bytes of K), rows srow + 32 i
+  const int cv = tid & 7, srow = tid >> 3;
+  int a_b[AR], a_y[AR], a_x[AR];
+  bool a_ok[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    int m = m0 + srow + 32 * i;
+    a_ok[i] = m < p.M;
+    if (spatial) {
+      int b = m / HW, rem = m - b * HW;
+      a_b[i] = b; a_y[i] = rem / p.W; a_x[i] = rem - a_y[i] * p.W;
+    } else {
+      a_b[i] = m; a_y[i] = 0; a_x[i] = 0;
+    }
+  }
+
+  uint4 ra[AR], rb[BR];
+
+  auto gload = [&](int kt) {
+    const int tap = kt / nch;
+    const int c = (kt - tap * nch) * BK + cv * VEC;
+    const bool cok = c < Ctot;
+    const int nvalid = Ctot - c;   // < VEC only for ragged K (taps == 1)
+    int dy = 0, dx = 0;
+    if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+    const bool second = c >= p.C0;
+    const void* src = second ? (const void*)A1 : (const void*)A0;
+    const long ld = second ? p.lda1 : p.lda0;
+    const int cc = second ? c - p.C0 : c;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      bool ok = a_ok[i] && cok;
+      long row = a_b[i];
+      if (spatial) {
+        int sy = a_y[i] + dy, sx = a_x[i] + dx;
+        ok = ok && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+        if (p.a_up) { sy >>= 1; sx >>= 1; }
+        row = ((long)a_b[i] * Hs + sy) * Ws + sx;
+      }
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) {
+        v = load_vec<TC, AF32>(src, row * ld + cc);
+        if (nvalid < VEC) v = mask_tail<TC>(v, nvalid);
+      }
+      ra[i] = v;
+    }
+    const long kb = (long)tap * Ctot + c;
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      int n = n0 + srow + 32 * j;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (n < p.N && cok) {
+        v = *(const uint4*)(Bw + (long)n * p.ldb + kb);
+        if (nvalid < VEC) v = mask_tail<TC>(v, nvalid);
+      }
+      rb[j] = v;
+    }
+  };
+  auto sstore = [&](int buf) {
+    unsigned char* a = As + buf * BM * ROWB;
+    unsigned char* b = Bs + buf * BN * ROWB;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *(uint4*)(a + (srow + 32 * i) * ROWB + cv * 16) = ra[i];
+#pragma unroll
+    for (int j = 0; j < BR; ++j) *(uint4*)(b + (srow + 32 * j) * ROWB + cv * 16) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const unsigned char* a = As + buf * BM * ROWB + (wm * (BM / 2) + lr) * ROWB + lh * 16;
+    const unsigned char* b = Bs + buf * BN * ROWB + (wn * (BN / 2) + lr) * ROWB + lh * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *(const uint4*)(a + i * 32 * ROWB + s * 32);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *(const uint4*)(b + j * 32 * ROWB + s * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<TC>::run(af[i], bf[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------
+  const long coff = (long)z0 * p.sC_z0 + (long)z1 * p.sC_z1;
+  const float* R = p.R ? p.R + (long)z0 * p.sR_z0 + (long)z1 * p.sR_z1 : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int row = m0 + wm * (BM / 2) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+      if (row >= p.M) continue;
+      const int bidx = row / p.rows_per_batch;
+      long rrow = row;
+      if (p.r_up) {
+        int rem = row - bidx * HW;
+        int y = rem / p.W, x = rem - y * p.W;
+        rrow = ((long)bidx * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
+      }
+      const float bm = p.bias_m ? p.bias_m[row] : 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * (BN / 2) + j * 32 + lr;
+        if (col >= p.N) continue;
+        float val = acc[i][j][v] + bm;
+        if (p.bias_n) val += p.bias_n[col];
+        if (p.bias_bn) val += p.bias_bn[(long)bidx * p.ld_bn + col];
+        if (R) val += R[rrow * p.ldr + col];
+        val *= p.alpha;
+        if (p.c_nchw) {
+          const int pix = row - bidx * p.rows_per_batch;
+          ((float*)p.C)[((long)bidx * p.N + col) * p.rows_per_batch + pix] = val * p.row_scale[bidx];
+        } else if (p.c_f32) {
+          ((float*)p.C)[coff + (long)row * p.ldc + col] = val;
+        } else {
+          ((TC*)p.C)[coff + (long)row * p.ldc + col] = from_f32<TC>(val);
+        }
+      }
+    }
+  }
+}
+
+template <typename TC, bool AF32, int BM, int BN>
+static int launch_t(const GemmParams& p, hipStream_t stream) {
+  constexpr int smem = 2 * (BM + BN) * ROWB;
+  static bool attr_set = false;
+  auto kern = gemm_kernel<TC, AF32, BM, BN>;
+  if (!attr_set) {
+    T2P_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nz0 * p.nz1);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+template <typename TC, bool AF32>
+static int launch_tile(const GemmParams& p, hipStream_t stream) {
+  // small problems: 64x64 tiles give more workgroups and waste less on ragged edges
+  const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.nz0 * p.nz1;
+  if (p.N <= 64 || p.M <= 64 || tiles128 < 128) return launch_t<TC, AF32, 64, 64>(p, stream);
+  return launch_t<TC, AF32, 128, 128>(p, stream);
+}
+
+int launch_gemm(const GemmParams& p, hipStream_t stream) {
+  const int vec = p.dtype == DT_F32 ? 4 : 8;
+  const int Ctot = p.C0 + p.C1;
+  T2P_REQUIRE(p.A0 && p.Bw && p.C, "null operand");
+  T2P_REQUIRE(p.M > 0 && p.N > 0 && Ctot > 0, "empty problem");
+  T2P_REQUIRE(p.taps == 1 || p.taps == 9, "taps must be 1 or 9");
+  T2P_REQUIRE(p.dtype != DT_F32 || p.a_f32, "fp32 compute takes fp32 sources");
+  T2P_REQUIRE(p.lda0 % vec == 0 && p.ldb % vec == 0, "row strides must be multiples of the 16-byte vector");
+  T2P_REQUIRE(p.lda0 >= ((p.C0 + vec - 1) / vec) * vec, "lda0 too small");
+  T2P_REQUIRE(p.ldb >= (long)(p.taps - 1) * Ctot + ((Ctot + vec - 1) / vec) * vec, "ldb too small");
+  if (p.A1) {
+    T2P_REQUIRE(p.C0 % vec == 0 && p.lda1 % vec == 0 && p.C1 % vec == 0, "concat sources must be vector aligned");
+    T2P_REQUIRE(p.nz0 * p.nz1 == 1, "batched GEMM takes a single A source");
+  } else {
+    T2P_REQUIRE(p.C1 == 0, "C1 without A1");
+  }
+  if (p.taps == 9) T2P_REQUIRE(Ctot % vec == 0, "3x3 convolution needs channels % vector == 0");
+  if (p.taps == 9 || p.a_up || p.r_up || p.c_nchw) {
+    T2P_REQUIRE(p.H > 0 && p.W > 0 && p.M % (p.H * p.W) == 0, "spatial mode needs H, W with M = batch*H*W");
+    T2P_REQUIRE(p.nz0 * p.nz1 == 1, "spatial modes are not batched");
+  }
+  if (p.a_up || p.r_up) T2P_REQUIRE(p.H % 2 == 0 && p.W % 2 == 0, "up-sampling needs even H, W");
+  if (p.r_up || p.c_nchw) T2P_REQUIRE(p.rows_per_batch == p.H * p.W, "rows_per_batch must be H*W");
+  T2P_REQUIRE(p.rows_per_batch > 0, "rows_per_batch");
+  T2P_REQUIRE(!p.c_nchw || (p.row_scale && p.c_f32), "nchw store needs row_scale and fp32 output");
+  T2P_REQUIRE(((uintptr_t)p.A0 % 16) == 0 && ((uintptr_t)p.Bw % 16) == 0 && ((uintptr_t)p.A1 % 16) == 0,
+              "operands must be 16-byte aligned");
+  T2P_REQUIRE((long)(p.M + 127) / 128 < 65536, "M too large for grid.y");
+  switch (p.dtype) {
+    case DT_F32: return launch_tile<float, true>(p, stream);
+    case DT_BF16: return p.a_f32 ? launch_tile<bf16_t, true>(p, stream) : launch_tile<bf16_t, false>(p, stream);
+    case DT_F16: return p.a_f32 ? launch_tile<f16_t, true>(p, stream) : launch_tile<f16_t, false>(p, stream);
+  }
+  set_last_error("launch_gemm: unknown dtype");
+  return T2P_ERR_INVALID;
+}
+
+}  // namespace t2p

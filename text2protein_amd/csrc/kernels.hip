@@ -1,0 +1,638 @@
+// HBM-bound kernels of the score network and the SDE update (gfx950).
+// All activations are NHWC ([batch][pixel][channel], channel contiguous) so that 64-lane
+// wavefronts read 16-byte vectors of consecutive channels (coalesced 1 KiB per wave-instruction).
+#include "t2p_kernels.h"
+
+namespace t2p {
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ inline double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float silu_f(float x) { return x / (1.f + expf(-x)); }
+
+template <typename T> __device__ inline void store4(T* p, float a, float b, float c, float d);
+template <> __device__ inline void store4<float>(float* p, float a, float b, float c, float d) {
+  *(float4*)p = make_float4(a, b, c, d);
+}
+template <> __device__ inline void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  uint2 u;
+  u.x = (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(b) << 16);
+  u.y = (uint32_t)f32_to_bf16_bits(c) | ((uint32_t)f32_to_bf16_bits(d) << 16);
+  *(uint2*)p = u;
+}
+template <> __device__ inline void store4<f16_t>(f16_t* p, float a, float b, float c, float d) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  h4 v = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
+  *(h4*)p = v;
+}
+
+// ================================== GroupNorm statistics ======================================
+// grid (nchunk, B, ceil(C / 1024)); each block: a slice of pixels x up to 1024 channels.  A
+// thread keeps a fixed 4-channel vector and strides over pixels (register accumulation), then
+// the block folds channels into groups through LDS.  Partials are combined in double by
+// gn_finalize_kernel in a fixed order (bitwise reproducible).
+static constexpr int GN_PIX_PER_CHUNK = 256;
+
+int gn_num_chunks(int HW) { return (HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK; }
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormArgs a, int nchunk) {
+  __shared__ float s_sum[32], s_sq[32];
+  const int C = a.C0 + a.C1;
+  const int cpg = C / a.G;
+  const int chunk = blockIdx.x, b = blockIdx.y, cblk = blockIdx.z;
+  const int c_lo = cblk * 1024;
+  const int nvec = min(C - c_lo, 1024) >> 2;          // 4-channel vectors handled by this block
+  const int ppi = 256 / nvec;                          // pixels per block iteration (>= 1)
+  const int tid = threadIdx.x;
+  if (tid < 32) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
+  __syncthreads();
+  const int p_lo = chunk * GN_PIX_PER_CHUNK, p_hi = min(a.HW, p_lo + GN_PIX_PER_CHUNK);
+  if (tid < ppi * nvec) {
+    const int v = tid % nvec, po = tid / nvec;
+    const int c = c_lo + v * 4;
+    const float* src; long ld; int cc;
+    if (c < a.C0) { src = a.x0; ld = a.C0; cc = c; } else { src = a.x1; ld = a.C1; cc = c - a.C0; }
+    float s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    for (int p = p_lo + po; p < p_hi; p += ppi) {
+      float4 t = *(const float4*)(src + ((long)b * a.HW + p) * ld + cc);
+      s0 += t.x; s1 += t.y; s2 += t.z; s3 += t.w;
+      q0 += t.x * t.x; q1 += t.y * t.y; q2 += t.z * t.z; q3 += t.w * t.w;
+    }
+    const int g0 = c / cpg, g3 = (c + 3) / cpg;
+    if (g0 == g3) {
+      atomicAdd(&s_sum[g0], (s0 + s1) + (s2 + s3));
+      atomicAdd(&s_sq[g0], (q0 + q1) + (q2 + q3));
+    } else {
+      atomicAdd(&s_sum[c / cpg], s0);       atomicAdd(&s_sq[c / cpg], q0);
+      atomicAdd(&s_sum[(c + 1) / cpg], s1); atomicAdd(&s_sq[(c + 1) / cpg], q1);
+      atomicAdd(&s_sum[(c + 2) / cpg], s2); atomicAdd(&s_sq[(c + 2) / cpg], q2);
+      atomicAdd(&s_sum[(c + 3) / cpg], s3); atomicAdd(&s_sq[(c + 3) / cpg], q3);
+    }
+  }
+  __syncthreads();
+  if (tid < a.G) {
+    // [B][cblk][nchunk][G][2]
+    float* dst = a.partial + ((((long)b * gridDim.z + cblk) * nchunk + chunk) * a.G + tid) * 2;
+    dst[0] = s_sum[tid];
+    dst[1] = s_sq[tid];
+  }
+}
+
+__global__ void gn_finalize_kernel(GroupNormArgs a, int nparts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over B * G
+  if (i >= a.B * a.G) return;
+  const int b = i / a.G, g = i - b * a.G;
+  double s = 0, q = 0;
+  for (int k = 0; k < nparts; ++k) {
+    const float* src = a.partial + (((long)b * nparts + k) * a.G + g) * 2;
+    s += src[0];
+    q += src[1];
+  }
+  const int C = a.C0 + a.C1;
+  const double n = (double)a.HW * (C / a.G);
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0) var = 0;
+  a.stats[2 * i] = (float)mean;
+  a.stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+}
+
+int launch_gn_stats(const GroupNormArgs& a, hipStream_t s) {
+  const int C = a.C0 + a.C1;
+  T2P_REQUIRE(a.x0 && a.partial && a.stats, "null pointer");
+  T2P_REQUIRE(a.G >= 1 && a.G <= 32 && C % a.G == 0, "GroupNorm groups must divide C and be <= 32");
+  T2P_REQUIRE(a.C0 % 4 == 0 && a.C1 % 4 == 0, "channels must be multiples of 4");
+  T2P_REQUIRE((a.C1 == 0) == (a.x1 == nullptr), "second source mismatch");
+  const int nchunk = gn_num_chunks(a.HW);
+  const int ncblk = (C + 1023) / 1024;
+  T2P_REQUIRE(ncblk == 1 || C % 1024 == 0 || (C - (ncblk - 1) * 1024) % 4 == 0, "channel blocking");
+  // a 1024-channel block must not split a source: C0 is either >= all blocks' range or aligned
+  T2P_REQUIRE(ncblk == 1 || a.C1 == 0 || a.C0 % 4 == 0, "concat alignment");
+  dim3 grid(nchunk, a.B, ncblk);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, a, nchunk);
+  const int tot = a.B * a.G;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 127) / 128), dim3(128), 0, s, a, nchunk * ncblk);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// ================================== GroupNorm apply (+SiLU, +2x2 mean) ==========================
+template <typename TO>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormApplyArgs a) {
+  const int C = a.C0 + a.C1;
+  const int nvec = C >> 2;
+  const int Ho = a.down ? a.H >> 1 : a.H, Wo = a.down ? a.W >> 1 : a.W;
+  const long total = (long)a.B * Ho * Wo * nvec;
+  const int cpg = C / a.G;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % nvec);
+    const long pix = idx / nvec;
+    const int b = (int)(pix / (Ho * Wo));
+    const int rem = (int)(pix - (long)b * Ho * Wo);
+    const int c = v * 4;
+    const float* src; long ld; int cc;
+    if (c < a.C0) { src = a.x0; ld = a.C0; cc = c; } else { src = a.x1; ld = a.C1; cc = c - a.C0; }
+    const float4 ga = *(const float4*)(a.gamma + c), be = *(const float4*)(a.beta + c);
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float* st = a.stats + ((long)b * a.G + (c + k) / cpg) * 2;
+      mean[k] = st[0]; rstd[k] = st[1];
+    }
+    float o[4] = {0, 0, 0, 0};
+    const int npx = a.down ? 4 : 1;
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    for (int q = 0; q < npx; ++q) {
+      const int iy = a.down ? 2 * oy + (q >> 1) : oy, ix = a.down ? 2 * ox + (q & 1) : ox;
+      const float4 t = *(const float4*)(src + (((long)b * a.H + iy) * a.W + ix) * ld + cc);
+      float y0 = (t.x - mean[0]) * rstd[0] * ga.x + be.x;
+      float y1 = (t.y - mean[1]) * rstd[1] * ga.y + be.y;
+      float y2 = (t.z - mean[2]) * rstd[2] * ga.z + be.z;
+      float y3 = (t.w - mean[3]) * rstd[3] * ga.w + be.w;
+      if (a.silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
+      o[0] += y0; o[1] += y1; o[2] += y2; o[3] += y3;
+    }
+    if (a.down) { o[0] *= 0.25f; o[1] *= 0.25f; o[2] *= 0.25f; o[3] *= 0.25f; }
+    store4<TO>((TO*)a.out + pix * C + c, o[0], o[1], o[2], o[3]);
+  }
+}
+
+static inline int ew_grid(long total, int block = 256) {
+  long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s) {
+  const int C = a.C0 + a.C1;
+  T2P_REQUIRE(a.x0 && a.stats && a.gamma && a.beta && a.out, "null pointer");
+  T2P_REQUIRE(a.C0 % 4 == 0 && a.C1 % 4 == 0 && C % a.G == 0, "channel constraints");
+  T2P_REQUIRE(!a.down || (a.H % 2 == 0 && a.W % 2 == 0), "down-sampling needs even H, W");
+  const long total = (long)a.B * (a.down ? a.H / 2 : a.H) * (a.down ? a.W / 2 : a.W) * (C / 4);
+  dim3 grid(ew_grid(total));
+  switch (a.dtype) {
+    case DT_F32: hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, a); break;
+    case DT_BF16: hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, a); break;
+    case DT_F16: hipLaunchKernelGGL(gn_apply_kernel<f16_t>, grid, dim3(256), 0, s, a); break;
+    default: set_last_error("gn_apply: bad dtype"); return T2P_ERR_INVALID;
+  }
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// ================================== LayerNorm ====================================================
+// one wavefront per row; three passes over an L1/L2-resident row (C <= a few thousand).
+template <typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* gamma, const float* beta,
+                                                        TO* out, long rows, int C, float eps) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + row * C;
+  float s = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    float4 t = *(const float4*)(xr + c);
+    s += (t.x + t.y) + (t.z + t.w);
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    float4 t = *(const float4*)(xr + c);
+    float a0 = t.x - mean, a1 = t.y - mean, a2 = t.z - mean, a3 = t.w - mean;
+    q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / C + eps);
+  for (int c = lane * 4; c < C; c += 256) {
+    float4 t = *(const float4*)(xr + c);
+    float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    store4<TO>(out + row * C + c, (t.x - mean) * rstd * g.x + b.x, (t.y - mean) * rstd * g.y + b.y,
+               (t.z - mean) * rstd * g.z + b.z, (t.w - mean) * rstd * g.w + b.w);
+  }
+}
+
+int launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int dtype, long rows, int C,
+                     float eps, hipStream_t s) {
+  T2P_REQUIRE(x && gamma && beta && out && C % 4 == 0 && rows > 0, "layernorm arguments");
+  dim3 grid((unsigned)((rows + 3) / 4));
+  switch (dtype) {
+    case DT_F32: hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, x, gamma, beta, (float*)out, rows, C, eps); break;
+    case DT_BF16: hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, s, x, gamma, beta, (bf16_t*)out, rows, C, eps); break;
+    case DT_F16: hipLaunchKernelGGL(layernorm_kernel<f16_t>, grid, dim3(256), 0, s, x, gamma, beta, (f16_t*)out, rows, C, eps); break;
+    default: set_last_error("layernorm: bad dtype"); return T2P_ERR_INVALID;
+  }
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// ================================== row softmax ====================================================
+// one wavefront per row; the row (<= 64 * SM_REGS elements) is held in registers, reductions by
+// wavefront shuffles.  Longer rows take the re-reading path.
+static constexpr int SM_REGS = 16;
+
+template <typename TO>
+__global__ __launch_bounds__(256) void softmax_kernel(const float* S, long lds, TO* P, long ldp, long rows, int n,
+                                                      float scale) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* sr = S + row * lds;
+  TO* pr = P + row * ldp;
+  if (n <= 64 * SM_REGS) {
+    float v[SM_REGS];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SM_REGS; ++i) {
+      const int c = lane + 64 * i;
+      v[i] = c < n ? sr[c] * scale : -INFINITY;
+      m = fmaxf(m, v[i]);
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_REGS; ++i) {
+      v[i] = (lane + 64 * i) < n ? expf(v[i] - m) : 0.f;
+      sum += v[i];
+    }
+    const float inv = 1.f / wave_sum(sum);
+#pragma unroll
+    for (int i = 0; i < SM_REGS; ++i) {
+      const int c = lane + 64 * i;
+      if (c < ldp) pr[c] = from_f32<TO>(v[i] * inv);   // zero beyond n (v == 0 there)
+    }
+  } else {
+    float m = -INFINITY;
+    for (int c = lane; c < n; c += 64) m = fmaxf(m, sr[c] * scale);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int c = lane; c < n; c += 64) sum += expf(sr[c] * scale - m);
+    const float inv = 1.f / wave_sum(sum);
+    for (int c = lane; c < ldp; c += 64) pr[c] = from_f32<TO>(c < n ? expf(sr[c] * scale - m) * inv : 0.f);
+  }
+}
+
+int launch_softmax(const float* S, long lds, void* P, long ldp, int dtype, long rows, int n, float scale,
+                   hipStream_t s) {
+  T2P_REQUIRE(S && P && rows > 0 && n > 0 && lds >= n && ldp >= n, "softmax arguments");
+  T2P_REQUIRE(ldp <= 64 * SM_REGS || n > 64 * SM_REGS, "padded row longer than the register path covers");
+  dim3 grid((unsigned)((rows + 3) / 4));
+  switch (dtype) {
+    case DT_F32: hipLaunchKernelGGL(softmax_kernel<float>, grid, dim3(256), 0, s, S, lds, (float*)P, ldp, rows, n, scale); break;
+    case DT_BF16: hipLaunchKernelGGL(softmax_kernel<bf16_t>, grid, dim3(256), 0, s, S, lds, (bf16_t*)P, ldp, rows, n, scale); break;
+    case DT_F16: hipLaunchKernelGGL(softmax_kernel<f16_t>, grid, dim3(256), 0, s, S, lds, (f16_t*)P, ldp, rows, n, scale); break;
+    default: set_last_error("softmax: bad dtype"); return T2P_ERR_INVALID;
+  }
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// ================================== GEGLU ============================================================
+template <typename TO>
+__global__ __launch_bounds__(256) void geglu_kernel(const float* u, TO* out, long rows, int inner) {
+  const int nvec = inner >> 2;
+  const long total = rows * nvec;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / nvec;
+    const int j = (int)(idx - r * nvec) * 4;
+    const float4 a = *(const float4*)(u + r * 2 * inner + j);
+    const float4 g = *(const float4*)(u + r * 2 * inner + inner + j);
+    auto gelu = [](float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); };
+    store4<TO>(out + r * inner + j, a.x * gelu(g.x), a.y * gelu(g.y), a.z * gelu(g.z), a.w * gelu(g.w));
+  }
+}
+
+int launch_geglu(const float* u, void* out, int dtype, long rows, int inner, hipStream_t s) {
+  T2P_REQUIRE(u && out && inner % 4 == 0 && rows > 0, "geglu arguments");
+  dim3 grid(ew_grid(rows * (inner / 4)));
+  switch (dtype) {
+    case DT_F32: hipLaunchKernelGGL(geglu_kernel<float>, grid, dim3(256), 0, s, u, (float*)out, rows, inner); break;
+    case DT_BF16: hipLaunchKernelGGL(geglu_kernel<bf16_t>, grid, dim3(256), 0, s, u, (bf16_t*)out, rows, inner); break;
+    case DT_F16: hipLaunchKernelGGL(geglu_kernel<f16_t>, grid, dim3(256), 0, s, u, (f16_t*)out, rows, inner); break;
+    default: set_last_error("geglu: bad dtype"); return T2P_ERR_INVALID;
+  }
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// ================================== 2x2 mean pooling ===================================================
+__global__ __launch_bounds__(256) void pool2x2_kernel(const float* x, float* out, int B, int H, int W, int C) {
+  const int nvec = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  const long total = (long)B * Ho * Wo * nvec;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % nvec);
+    const long pix = idx / nvec;
+    const int b = (int)(pix / (Ho * Wo));
+    const int rem = (int)(pix - (long)b * Ho * Wo);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    const float* p = x + (((long)b * H + 2 * oy) * W + 2 * ox) * C + v * 4;
+    const float4 a = *(const float4*)p, b1 = *(const float4*)(p + C);
+    const float4 c = *(const float4*)(p + (long)W * C), d = *(const float4*)(p + (long)W * C + C);
+    // torch.mean over the (2, 2) window: sum in row-major window order, then divide
+    *(float4*)(out + pix * C + v * 4) = make_float4((a.x + b1.x + c.x + d.x) * 0.25f, (a.y + b1.y + c.y + d.y) * 0.25f,
+                                                     (a.z + b1.z + c.z + d.z) * 0.25f, (a.w + b1.w + c.w + d.w) * 0.25f);
+  }
+}
+
+int launch_pool2x2(const float* x, float* out, int B, int H, int W, int C, hipStream_t s) {
+  T2P_REQUIRE(x && out && C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "pool2x2 arguments");
+  hipLaunchKernelGGL(pool2x2_kernel, dim3(ew_grid((long)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, s, x, out, B, H, W, C);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// ================================== NCHW -> padded NHWC ==================================================
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, float* out, int B, int C, int HW, int Cpad) {
+  const long total = (long)B * HW;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(idx / HW);
+    const int p = (int)(idx - (long)b * HW);
+    for (int c = 0; c < Cpad; ++c) out[idx * Cpad + c] = c < C ? x[((long)b * C + c) * HW + p] : 0.f;
+  }
+}
+
+int launch_nchw_to_nhwc(const float* x, float* out, int B, int C, int HW, int Cpad, hipStream_t s) {
+  T2P_REQUIRE(x && out && Cpad >= C, "nchw_to_nhwc arguments");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid((long)B * HW)), dim3(256), 0, s, x, out, B, C, HW, Cpad);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// ================================== time embedding ========================================================
+__global__ void timestep_embedding_kernel(const int* labels, const int* step_counter, float* emb, int rows, int dim) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * dim) return;
+  const int r = i / dim, k = i - r * dim;
+  const float t = (float)(labels ? labels[r] : *step_counter);
+  // reference: emb = log(10000) / (half - 1) as a python float, then exp(arange * -emb) in fp32
+  const float e = (float)(9.210340371976184 / (double)(half - 1));
+  float val = 0.f;
+  if (k < 2 * half) {
+    const int kk = k < half ? k : k - half;
+    const float f = expf((float)kk * -e);
+    const float arg = t * f;
+    val = k < half ? sinf(arg) : cosf(arg);
+  }
+  emb[i] = val;
+}
+
+int launch_timestep_embedding(const int* labels, const int* step_counter, float* emb, int rows, int dim, hipStream_t s) {
+  T2P_REQUIRE((labels || step_counter) && emb && dim >= 4, "timestep embedding arguments");
+  const int tot = rows * dim;
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, labels, step_counter, emb, rows, dim);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// one wavefront per output feature n, looping over rows; K split over lanes
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* in, const float* W, const float* bias, float* out,
+                                                           int rows, int K, int N, int silu) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int lane = threadIdx.x & 63;
+  const float* w = W + (long)n * K;
+  for (int r = 0; r < rows; ++r) {
+    const float* x = in + (long)r * K;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      float v = x[k];
+      if (silu) v = silu_f(v);
+      acc += v * w[k];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[(long)r * N + n] = acc + (bias ? bias[n] : 0.f);
+  }
+}
+
+int launch_small_linear(const float* in, const float* W, const float* bias, float* out, int rows, int K, int N, int silu,
+                        hipStream_t s) {
+  T2P_REQUIRE(in && W && out && rows > 0 && K > 0 && N > 0, "small_linear arguments");
+  hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, s, in, W, bias, out, rows, K, N, silu);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// ================================== SDE update ===============================================================
+static constexpr int NORM_BLOCKS = 64;   // partial blocks per sample
+
+__global__ __launch_bounds__(256) void langevin_sq_kernel(const float* grad, const float* noise, long per_sample, float* sq_ws) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const float* g = grad + (long)b * per_sample;
+  const float* z = noise + (long)b * per_sample;
+  float sg = 0.f, sz = 0.f;
+  for (long i = (long)blk * 256 + threadIdx.x; i < per_sample; i += (long)NORM_BLOCKS * 256) {
+    const float a = g[i], c = z[i];
+    sg += a * a;
+    sz += c * c;
+  }
+  sg = wave_sum(sg);
+  sz = wave_sum(sz);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red[0][w] = sg; red[1][w] = sz; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sq_ws[((long)b * NORM_BLOCKS + blk) * 2 + 0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    sq_ws[((long)b * NORM_BLOCKS + blk) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+__global__ __launch_bounds__(64) void langevin_norm_finalize_kernel(const float* sq_ws, int B, float* sums) {
+  const int lane = threadIdx.x;
+  double tg = 0, tz = 0;
+  for (int b = 0; b < B; ++b) {
+    double g = (double)sq_ws[((long)b * NORM_BLOCKS + lane) * 2 + 0];
+    double z = (double)sq_ws[((long)b * NORM_BLOCKS + lane) * 2 + 1];
+    g = wave_sum_d(g);
+    z = wave_sum_d(z);
+    tg += sqrt(g);
+    tz += sqrt(z);
+  }
+  if (lane == 0) { sums[0] = (float)tg; sums[1] = (float)tz; }
+}
+
+int launch_langevin_norms(const float* grad, const float* noise, int B, long per_sample, float* sq_ws, float* sums,
+                          hipStream_t s) {
+  T2P_REQUIRE(grad && noise && sq_ws && sums && B > 0 && per_sample > 0, "langevin_norms arguments");
+  static_assert(NORM_BLOCKS == 64, "finalize assumes one partial per lane");
+  hipLaunchKernelGGL(langevin_sq_kernel, dim3(NORM_BLOCKS, B), dim3(256), 0, s, grad, noise, per_sample, sq_ws);
+  hipLaunchKernelGGL(langevin_norm_finalize_kernel, dim3(1), dim3(64), 0, s, sq_ws, B, sums);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+__global__ __launch_bounds__(256) void langevin_update_kernel(SdeUpdateArgs a, const float* sums, float batch_total, float snr,
+                                                              float alpha) {
+  // step_size = (snr * noise_norm / grad_norm)^2 * 2 * alpha   (sampling.py:195)
+  const float gn = sums[0] / batch_total, nn = sums[1] / batch_total;
+  const float r = snr * nn / gn;
+  const float step = r * r * 2.f * alpha;
+  const float nscale = sqrtf(step * 2.f);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) {
+    const float x = a.x[i];
+    const float xm = x + step * a.score[i];
+    float xn = xm + nscale * a.noise[i];
+    if (a.mask && !a.mask[i]) xn = a.x_initial[i];
+    a.x_out[i] = xn;
+    if (a.x_mean_out) a.x_mean_out[i] = xm;
+  }
+}
+
+int launch_langevin_update(const SdeUpdateArgs& a, const float* sums, float batch_total, float snr, float alpha,
+                           hipStream_t s) {
+  T2P_REQUIRE(a.x && a.score && a.noise && a.x_out && sums && a.n > 0, "langevin_update arguments");
+  T2P_REQUIRE(!a.mask || a.x_initial, "mask needs x_initial");
+  hipLaunchKernelGGL(langevin_update_kernel, dim3(ew_grid(a.n)), dim3(256), 0, s, a, sums, batch_total, snr, alpha);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+__global__ __launch_bounds__(256) void predictor_update_kernel(SdeUpdateArgs a, const float* G_table, const int* step_counter,
+                                                               float G_value, int probability_flow) {
+  const float G = G_table ? G_table[*step_counter] : G_value;
+  const float g2 = G * G * (probability_flow ? 0.5f : 1.f);
+  const float gz = probability_flow ? 0.f : G;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) {
+    // rev_f = -G^2 * score ; x_mean = x - rev_f ; x = x_mean + G z   (sde_lib.py:96-101, sampling.py:162-167)
+    const float xm = a.x[i] + g2 * a.score[i];
+    float xn = xm + gz * a.noise[i];
+    if (a.mask && !a.mask[i]) xn = a.x_initial[i];
+    a.x_out[i] = xn;
+    if (a.x_mean_out) a.x_mean_out[i] = xm;
+  }
+}
+
+int launch_predictor_update(const SdeUpdateArgs& a, const float* G_table, const int* step_counter, float G_value,
+                            int probability_flow, hipStream_t s) {
+  T2P_REQUIRE(a.x && a.score && a.noise && a.x_out && a.n > 0, "predictor_update arguments");
+  T2P_REQUIRE(!a.mask || a.x_initial, "mask needs x_initial");
+  T2P_REQUIRE(!G_table || step_counter, "G_table needs the step counter");
+  hipLaunchKernelGGL(predictor_update_kernel, dim3(ew_grid(a.n)), dim3(256), 0, s, a, G_table, step_counter, G_value,
+                     probability_flow);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// ---- Philox4x32-10 + Box-Muller -------------------------------------------------------------------------------
+__device__ inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ __launch_bounds__(256) void philox_normal_kernel(float* out, long n, unsigned long long seed, unsigned long long stream,
+                                                            const int* step_counter) {
+  const uint32_t step = step_counter ? (uint32_t)*step_counter : 0u;
+  const long nq = (n + 3) / 4;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)((unsigned long long)q >> 32), (uint32_t)stream, step};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    float z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+      const float u2 = (float)(c[2 * h + 1] >> 8) * (1.0f / 16777216.0f);         // [0, 1)
+      const float rad = sqrtf(-2.f * logf(u1));
+      float sn, cs;
+      sincosf(6.283185307179586f * u2, &sn, &cs);
+      z[2 * h] = rad * cs;
+      z[2 * h + 1] = rad * sn;
+    }
+    const long i = q * 4;
+    if (i + 3 < n) {
+      *(float4*)(out + i) = make_float4(z[0], z[1], z[2], z[3]);
+    } else {
+      for (int k = 0; k < 4 && i + k < n; ++k) out[i + k] = z[k];
+    }
+  }
+}
+
+int launch_philox_normal(float* out, long n, unsigned long long seed, unsigned long long stream, const int* step_counter,
+                         hipStream_t s) {
+  T2P_REQUIRE(out && n > 0 && ((uintptr_t)out % 16) == 0, "philox_normal arguments");
+  hipLaunchKernelGGL(philox_normal_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, s, out, n, seed, stream, step_counter);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+__global__ void add_int_kernel(int* c, int d) { *c += d; }
+int launch_add_int(int* counter, int delta, hipStream_t s) {
+  hipLaunchKernelGGL(add_int_kernel, dim3(1), dim3(1), 0, s, counter, delta);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float* x, long n, float a) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= a;
+}
+int launch_scale(float* x, long n, float a, hipStream_t s) {
+  hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n)), dim3(256), 0, s, x, n, a);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+
+// ================================== fp32 -> compute dtype ====================================================
+template <typename TO>
+__global__ __launch_bounds__(256) void convert_kernel(const float* in, TO* out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    out[i] = from_f32<TO>(in[i]);
+}
+int launch_convert(const float* in, void* out, int dtype, long n, hipStream_t s) {
+  T2P_REQUIRE(in && out && n > 0, "convert arguments");
+  dim3 grid(ew_grid(n));
+  switch (dtype) {
+    case DT_F32: hipLaunchKernelGGL(convert_kernel<float>, grid, dim3(256), 0, s, in, (float*)out, n); break;
+    case DT_BF16: hipLaunchKernelGGL(convert_kernel<bf16_t>, grid, dim3(256), 0, s, in, (bf16_t*)out, n); break;
+    case DT_F16: hipLaunchKernelGGL(convert_kernel<f16_t>, grid, dim3(256), 0, s, in, (f16_t*)out, n); break;
+    default: set_last_error("convert: bad dtype"); return T2P_ERR_INVALID;
+  }
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// out[b] = table[label_b]  (1 / sigma of the sample's time label; ncsnpp.py:223,259-261)
+__global__ void gather_label_kernel(const int* labels, const int* step_counter, const float* table, float* out, int B, int N) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int l = labels ? labels[b] : *step_counter;
+  l = l < 0 ? 0 : (l >= N ? N - 1 : l);
+  out[b] = table[l];
+}
+int launch_gather_label(const int* labels, const int* step_counter, const float* table, float* out, int B, int N, hipStream_t s) {
+  T2P_REQUIRE((labels || step_counter) && table && out && B > 0, "gather_label arguments");
+  hipLaunchKernelGGL(gather_label_kernel, dim3((B + 63) / 64), dim3(64), 0, s, labels, step_counter, table, out, B, N);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// x = where(mask, x, x_initial)   (sampling.py:283,285,287)
+__global__ __launch_bounds__(256) void apply_mask_kernel(float* x, const unsigned char* mask, const float* x_initial, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    if (!mask[i]) x[i] = x_initial[i];
+}
+int launch_apply_mask(float* x, const unsigned char* mask, const float* x_initial, long n, hipStream_t s) {
+  T2P_REQUIRE(x && mask && x_initial && n > 0, "apply_mask arguments");
+  hipLaunchKernelGGL(apply_mask_kernel, dim3(ew_grid(n)), dim3(256), 0, s, x, mask, x_initial, n);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+}  // namespace t2p

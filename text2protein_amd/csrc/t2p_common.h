@@ -1,0 +1,123 @@
+// Shared declarations for the text2protein HIP library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace t2p {
+
+// ---- compute dtypes ------------------------------------------------------------------------
+// The residual stream, statistics, softmax inputs and accumulators are always fp32.  GEMM
+// operands (activations after a norm, weights, attention probabilities) are stored in the
+// engine's "compute dtype": fp32 (exact-f32 MFMA), bf16 or fp16 (16-bit MFMA, fp32 accumulate).
+enum DType : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
+
+inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+
+struct bf16_t { uint16_t v; };
+struct f16_t { _Float16 v; };
+
+template <typename T> struct dtype_of;
+template <> struct dtype_of<float> { static constexpr int value = DT_F32; };
+template <> struct dtype_of<bf16_t> { static constexpr int value = DT_BF16; };
+template <> struct dtype_of<f16_t> { static constexpr int value = DT_F16; };
+
+__host__ __device__ inline uint16_t f32_to_bf16_bits(float f) {
+  // round-to-nearest-even; NaN stays NaN (quiet)
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__host__ __device__ inline float bf16_bits_to_f32(uint16_t b) {
+  uint32_t u = ((uint32_t)b) << 16;
+  return __builtin_bit_cast(float, u);
+}
+
+template <typename T> __host__ __device__ inline T from_f32(float f);
+template <> __host__ __device__ inline float from_f32<float>(float f) { return f; }
+template <> __host__ __device__ inline bf16_t from_f32<bf16_t>(float f) { return bf16_t{f32_to_bf16_bits(f)}; }
+template <> __host__ __device__ inline f16_t from_f32<f16_t>(float f) { return f16_t{(_Float16)f}; }
+
+__host__ __device__ inline float to_f32(float f) { return f; }
+__host__ __device__ inline float to_f32(bf16_t b) { return bf16_bits_to_f32(b.v); }
+__host__ __device__ inline float to_f32(f16_t h) { return (float)h.v; }
+
+// ---- error handling --------------------------------------------------------------------------
+void set_last_error(const std::string& msg);
+const char* get_last_error();
+
+#define T2P_OK 0
+#define T2P_ERR_INVALID 1
+#define T2P_ERR_HIP 2
+#define T2P_ERR_STATE 3
+
+#define T2P_HIP_CHECK(expr)                                                                   \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      ::t2p::set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " at " +      \
+                            __FILE__ + ":" + std::to_string(__LINE__));                       \
+      return T2P_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+#define T2P_REQUIRE(cond, msg)                                                                \
+  do {                                                                                        \
+    if (!(cond)) {                                                                            \
+      ::t2p::set_last_error(std::string("requirement failed: ") + #cond + " -- " + (msg) +    \
+                            " at " + __FILE__ + ":" + std::to_string(__LINE__));              \
+      return T2P_ERR_INVALID;                                                                 \
+    }                                                                                         \
+  } while (0)
+
+#define T2P_TRY(expr)                                                                         \
+  do {                                                                                        \
+    int _rc = (expr);                                                                         \
+    if (_rc != T2P_OK) return _rc;                                                            \
+  } while (0)
+
+// ---- GEMM / implicit-GEMM convolution ------------------------------------------------------------
+// C[z][m][n] = alpha * ( sum_k A[z][m][k] * Bw[z][n][k] + bias_n[n] + bias_m[m]
+//                        + bias_bn[m / rows_per_batch][n] + R[z][res_row(m)][n] )
+// A is gathered: row m is pixel (b, y, x) of an NHWC map; with taps == 9 the K axis is
+// (tap, channel) and the source pixel is (y + dy, x + dx) with zero padding (3x3 convolution,
+// reference layers.py:89-95); a_up reads the source at half resolution (nearest up-sampling,
+// layers.py:179-183).  The channel axis may be the concatenation of two sources (U-Net skip
+// concat, reference ncsnpp.py:250) without materialising the concat.
+struct GemmParams {
+  const void* A0 = nullptr;  // [rows][lda0], C0 channels
+  const void* A1 = nullptr;  // optional second source, C1 channels
+  int a_f32 = 0;             // sources are fp32 (converted to the compute dtype while staging)
+  int C0 = 0, C1 = 0;
+  long lda0 = 0, lda1 = 0;
+  int taps = 1;              // 1 or 9
+  int H = 0, W = 0;          // output map size (spatial modes)
+  int a_up = 0;              // source map is (H/2, W/2)
+  const void* Bw = nullptr;  // [N][ldb] compute dtype, K index = tap * (C0 + C1) + c
+  long ldb = 0;
+  int M = 0, N = 0;
+  // batching over blockIdx.z = z0 * nz1 + z1
+  int nz0 = 1, nz1 = 1;
+  long sA_z0 = 0, sA_z1 = 0, sB_z0 = 0, sB_z1 = 0, sC_z0 = 0, sC_z1 = 0, sR_z0 = 0, sR_z1 = 0;
+  // epilogue
+  const float* bias_n = nullptr;
+  const float* bias_m = nullptr;
+  const float* bias_bn = nullptr;  // [batch][ld_bn]
+  int rows_per_batch = 1;
+  long ld_bn = 0;
+  const float* R = nullptr;  // fp32 residual
+  long ldr = 0;
+  int r_up = 0;              // residual lives at half resolution (uses H, W, rows_per_batch = H*W)
+  float alpha = 1.f;
+  void* C = nullptr;
+  int c_f32 = 1;             // output fp32 (else compute dtype)
+  long ldc = 0;
+  int c_nchw = 0;            // store C as [batch][N][H*W] fp32, scaled by row_scale[batch]
+  const float* row_scale = nullptr;
+  int dtype = DT_F32;        // compute dtype of A (if !a_f32), Bw and C (if !c_f32)
+};
+
+int launch_gemm(const GemmParams& p, hipStream_t stream);
+
+}  // namespace t2p

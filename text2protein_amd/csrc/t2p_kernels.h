@@ -1,0 +1,93 @@
+// Launchers for the non-GEMM kernels of the score network and the SDE update.
+#pragma once
+#include "t2p_common.h"
+
+namespace t2p {
+
+// ---- GroupNorm (reference nn.GroupNorm, layers.py:282,292; attention.py:77; ncsnpp.py:214) ----
+// x is NHWC fp32, optionally the channel-concat of two sources.  stats = [B][G][2] (mean, rstd).
+struct GroupNormArgs {
+  const float* x0 = nullptr; const float* x1 = nullptr;
+  int C0 = 0, C1 = 0;
+  int B = 0, HW = 0;       // input pixels per sample
+  int G = 0;
+  float eps = 1e-6f;
+  float* partial = nullptr;  // workspace [B][nchunk][G][2], nchunk = gn_num_chunks(HW)
+  float* stats = nullptr;    // [B][G][2]
+};
+int gn_num_chunks(int HW);
+int launch_gn_stats(const GroupNormArgs& a, hipStream_t s);
+
+struct GroupNormApplyArgs {
+  const float* x0 = nullptr; const float* x1 = nullptr;
+  int C0 = 0, C1 = 0, B = 0, H = 0, W = 0, G = 0;
+  const float* stats = nullptr;       // [B][G][2]
+  const float* gamma = nullptr; const float* beta = nullptr;
+  int silu = 0;
+  int down = 0;                        // 2x2 mean of the activated map (layers.py:185-188)
+  void* out = nullptr;                 // [B][H'*W'][C] in `dtype`
+  int dtype = DT_F32;
+};
+int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s);
+
+// ---- LayerNorm over the last axis (attention.py:203-205), eps 1e-5 ---------------------------
+int launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int dtype,
+                     long rows, int C, float eps, hipStream_t s);
+
+// ---- row softmax: P[r][0:n] = softmax(scale * S[r][0:n]); P[r][n:ldp] = 0 ----------------------
+int launch_softmax(const float* S, long lds, void* P, long ldp, int dtype, long rows, int n, float scale,
+                   hipStream_t s);
+
+// ---- GEGLU (attention.py:37-44): out[r][j] = u[r][j] * gelu_erf(u[r][inner + j]) ----------------
+int launch_geglu(const float* u, void* out, int dtype, long rows, int inner, hipStream_t s);
+
+// ---- 2x2 mean pooling of an NHWC fp32 map (skip branch of a down block, layers.py:309-311) ------
+int launch_pool2x2(const float* x, float* out, int B, int H, int W, int C, hipStream_t s);
+
+// ---- NCHW fp32 (B,C,L,L) -> NHWC fp32 [B][L*L][Cpad], zero padded channels -----------------------
+int launch_nchw_to_nhwc(const float* x, float* out, int B, int C, int HW, int Cpad, hipStream_t s);
+
+// ---- time embedding ------------------------------------------------------------------------------
+// emb[r][:] = [sin(t f_k) | cos(t f_k)] (layers.py:97-111); label of row r = labels ? labels[r]
+// : *step_counter (device scalar) -- the sampler advances a device-side counter so that a
+// captured graph of one PC step can be replayed.
+int launch_timestep_embedding(const int* labels, const int* step_counter, float* emb, int rows, int dim,
+                              hipStream_t s);
+// out[r][n] = bias[n] + sum_k act(in[r][k]) * W[n][k]   (fp32; act = SiLU when silu != 0)
+int launch_small_linear(const float* in, const float* W, const float* bias, float* out, int rows, int K, int N,
+                        int silu, hipStream_t s);
+
+// ---- reverse-diffusion predictor + Langevin corrector (sampling.py:157-199) ------------------------
+// sums[0] = sum_b ||grad_b||_2, sums[1] = sum_b ||noise_b||_2  (per-sample norms, summed over b)
+int launch_langevin_norms(const float* grad, const float* noise, int B, long per_sample, float* sq_ws,
+                          float* sums, hipStream_t s);
+struct SdeUpdateArgs {
+  const float* x = nullptr;        // current state (B, C, L, L) fp32
+  const float* score = nullptr;    // network output
+  const float* noise = nullptr;    // standard normal draws
+  const unsigned char* mask = nullptr;  // conditional_mask (1 = free), may be null
+  const float* x_initial = nullptr;
+  float* x_out = nullptr;
+  float* x_mean_out = nullptr;     // un-masked x_mean (masking of the final x_mean: sampling.py:287)
+  long n = 0;                      // total elements
+};
+// corrector: step = (snr * mean_norm_noise / mean_norm_grad)^2 * 2 * alpha, with the two means
+// = sums[] / batch_total (batch_total may exceed the local batch: global-batch semantics)
+int launch_langevin_update(const SdeUpdateArgs& a, const float* sums, float batch_total, float snr, float alpha,
+                           hipStream_t s);
+// predictor: x_mean = x + G^2 * score * (0.5 if probability_flow); x = x_mean + (0 if pf else G) z
+// G = G_table[*step_counter] when G_table != null, else G_value
+int launch_predictor_update(const SdeUpdateArgs& a, const float* G_table, const int* step_counter, float G_value,
+                            int probability_flow, hipStream_t s);
+// noise[i] = N(0,1) from Philox4x32-10 keyed by (seed, stream); counter = element index / 4
+int launch_philox_normal(float* out, long n, unsigned long long seed, unsigned long long stream,
+                         const int* step_counter, hipStream_t s);
+int launch_add_int(int* counter, int delta, hipStream_t s);
+int launch_scale(float* x, long n, float a, hipStream_t s);
+
+int launch_convert(const float* in, void* out, int dtype, long n, hipStream_t s);
+int launch_gather_label(const int* labels, const int* step_counter, const float* table, float* out, int B, int N,
+                        hipStream_t s);
+int launch_apply_mask(float* x, const unsigned char* mask, const float* x_initial, long n, hipStream_t s);
+
+}  // namespace t2p
