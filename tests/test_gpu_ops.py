@@ -20,8 +20,21 @@ def lib():
     return _lib.load()
 
 
+_KEEP = []
+
+
 def dev(t):
-    return t.contiguous().to("cuda")
+    """Copy to the GPU and keep the tensor alive until the test ends (raw pointers are passed to C)."""
+    d = t.contiguous().to("cuda")
+    _KEEP.append(d)
+    return d
+
+
+@pytest.fixture(autouse=True)
+def _release_device_tensors():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
 
 
 def P(t):
