@@ -136,11 +136,20 @@ int t2p_op_attention(int dtype, const void* q, int64_t ldq, const void* k, int64
 int t2p_op_langevin(const float* x, const float* grad, const float* noise, const uint8_t* mask,
                     const float* x_initial, float* x_out, float* x_mean_out, int batch, int64_t per_sample,
                     float snr, float alpha, float* sums_out /* device float[2], may be NULL */, void* stream);
+/* split form: norms -> (optional all-reduce of sums over ranks by the caller) -> update.
+ * workspace: device float[batch * 128]; sums: device float[2] = {sum_b ||grad_b||, sum_b ||noise_b||} */
+int t2p_op_langevin_norms(const float* grad, const float* noise, int batch, int64_t per_sample, float* workspace,
+                          float* sums, void* stream);
+int t2p_op_langevin_update(const float* x, const float* grad, const float* noise, const uint8_t* mask,
+                           const float* x_initial, float* x_out, float* x_mean_out, int64_t n, const float* sums,
+                           float batch_total, float snr, float alpha, void* stream);
 int t2p_op_predictor(const float* x, const float* score, const float* noise, const uint8_t* mask,
                      const float* x_initial, float* x_out, float* x_mean_out, int64_t n, float G,
                      int probability_flow, void* stream);
 int t2p_op_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
 int t2p_op_convert(const float* in, void* out, int dtype, int64_t n, void* stream);
+/* x = where(mask, x, x_initial) (sampling.py:283,285,287) */
+int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,9 @@ SIGNATURES = {
     "t2p_op_attention_ws": (_i64, [_i, _i, _i, _i, _i]),
     "t2p_op_attention": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "t2p_op_langevin": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp]),
+    "t2p_op_langevin_norms": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    "t2p_op_langevin_update": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _vp]),
+    "t2p_op_apply_mask": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "t2p_op_predictor": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _i, _vp]),
     "t2p_op_philox_normal": (_i, [_vp, _i64, _u64, _u64, _vp]),
     "t2p_op_convert": (_i, [_vp, _vp, _i, _i64, _vp]),

@@ -260,6 +260,24 @@ int t2p_op_langevin(const float* x, const float* grad, const float* noise, const
   API_END
 }
 
+int t2p_op_langevin_norms(const float* grad, const float* noise, int batch, int64_t per_sample, float* workspace,
+                          float* sums, void* stream) {
+  API_BEGIN
+  return launch_langevin_norms(grad, noise, batch, per_sample, workspace, sums, (hipStream_t)stream);
+  API_END
+}
+
+int t2p_op_langevin_update(const float* x, const float* grad, const float* noise, const uint8_t* mask,
+                           const float* x_initial, float* x_out, float* x_mean_out, int64_t n, const float* sums,
+                           float batch_total, float snr, float alpha, void* stream) {
+  API_BEGIN
+  SdeUpdateArgs a;
+  a.x = x; a.score = grad; a.noise = noise; a.mask = mask; a.x_initial = x_initial; a.x_out = x_out;
+  a.x_mean_out = x_mean_out; a.n = n;
+  return launch_langevin_update(a, sums, batch_total, snr, alpha, (hipStream_t)stream);
+  API_END
+}
+
 int t2p_op_predictor(const float* x, const float* score, const float* noise, const uint8_t* mask, const float* x_initial,
                      float* x_out, float* x_mean_out, int64_t n, float G, int probability_flow, void* stream) {
   API_BEGIN
@@ -279,6 +297,12 @@ int t2p_op_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_i
 int t2p_op_convert(const float* in, void* out, int dtype, int64_t n, void* stream) {
   API_BEGIN
   return launch_convert(in, out, dtype, n, (hipStream_t)stream);
+  API_END
+}
+
+int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int64_t n, void* stream) {
+  API_BEGIN
+  return launch_apply_mask(x, mask, x_initial, n, (hipStream_t)stream);
   API_END
 }
 

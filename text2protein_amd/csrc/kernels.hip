@@ -41,52 +41,53 @@ template <> __device__ inline void store4<f16_t>(f16_t* p, float a, float b, flo
 // ================================== GroupNorm statistics ======================================
 // grid (nchunk, B, ceil(C / 1024)); each block: a slice of pixels x up to 1024 channels.  A
 // thread keeps a fixed 4-channel vector and strides over pixels (register accumulation), then
-// the block folds channels into groups through LDS.  Partials are combined in double by
-// gn_finalize_kernel in a fixed order (bitwise reproducible).
+// the block folds channels into groups through LDS in a fixed order.  Partials are combined in
+// double by gn_finalize_kernel, also in a fixed order: results are bitwise reproducible.
 static constexpr int GN_PIX_PER_CHUNK = 256;
 
 int gn_num_chunks(int HW) { return (HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK; }
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormArgs a, int nchunk) {
-  __shared__ float s_sum[32], s_sq[32];
+  __shared__ float s_part[256][8];   // per thread: sum[4], sumsq[4] of its 4-channel vector
   const int C = a.C0 + a.C1;
   const int cpg = C / a.G;
   const int chunk = blockIdx.x, b = blockIdx.y, cblk = blockIdx.z;
   const int c_lo = cblk * 1024;
-  const int nvec = min(C - c_lo, 1024) >> 2;          // 4-channel vectors handled by this block
+  const int cw = min(C - c_lo, 1024);                  // channels handled by this block
+  const int nvec = cw >> 2;                            // 4-channel vectors
   const int ppi = 256 / nvec;                          // pixels per block iteration (>= 1)
   const int tid = threadIdx.x;
-  if (tid < 32) { s_sum[tid] = 0.f; s_sq[tid] = 0.f; }
-  __syncthreads();
   const int p_lo = chunk * GN_PIX_PER_CHUNK, p_hi = min(a.HW, p_lo + GN_PIX_PER_CHUNK);
+  float s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
   if (tid < ppi * nvec) {
     const int v = tid % nvec, po = tid / nvec;
     const int c = c_lo + v * 4;
     const float* src; long ld; int cc;
     if (c < a.C0) { src = a.x0; ld = a.C0; cc = c; } else { src = a.x1; ld = a.C1; cc = c - a.C0; }
-    float s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
     for (int p = p_lo + po; p < p_hi; p += ppi) {
       float4 t = *(const float4*)(src + ((long)b * a.HW + p) * ld + cc);
       s0 += t.x; s1 += t.y; s2 += t.z; s3 += t.w;
       q0 += t.x * t.x; q1 += t.y * t.y; q2 += t.z * t.z; q3 += t.w * t.w;
     }
-    const int g0 = c / cpg, g3 = (c + 3) / cpg;
-    if (g0 == g3) {
-      atomicAdd(&s_sum[g0], (s0 + s1) + (s2 + s3));
-      atomicAdd(&s_sq[g0], (q0 + q1) + (q2 + q3));
-    } else {
-      atomicAdd(&s_sum[c / cpg], s0);       atomicAdd(&s_sq[c / cpg], q0);
-      atomicAdd(&s_sum[(c + 1) / cpg], s1); atomicAdd(&s_sq[(c + 1) / cpg], q1);
-      atomicAdd(&s_sum[(c + 2) / cpg], s2); atomicAdd(&s_sq[(c + 2) / cpg], q2);
-      atomicAdd(&s_sum[(c + 3) / cpg], s3); atomicAdd(&s_sq[(c + 3) / cpg], q3);
-    }
   }
+  s_part[tid][0] = s0; s_part[tid][1] = s1; s_part[tid][2] = s2; s_part[tid][3] = s3;
+  s_part[tid][4] = q0; s_part[tid][5] = q1; s_part[tid][6] = q2; s_part[tid][7] = q3;
   __syncthreads();
   if (tid < a.G) {
+    // fold this block's channels of group `tid` in a fixed order (bitwise reproducible)
+    const int g_lo = max(tid * cpg, c_lo), g_hi = min((tid + 1) * cpg, c_lo + cw);
+    float s = 0.f, q = 0.f;
+    for (int c = g_lo; c < g_hi; ++c) {
+      const int v = (c - c_lo) >> 2, k = (c - c_lo) & 3;
+      for (int po = 0; po < ppi; ++po) {
+        s += s_part[po * nvec + v][k];
+        q += s_part[po * nvec + v][4 + k];
+      }
+    }
     // [B][cblk][nchunk][G][2]
     float* dst = a.partial + ((((long)b * gridDim.z + cblk) * nchunk + chunk) * a.G + tid) * 2;
-    dst[0] = s_sum[tid];
-    dst[1] = s_sq[tid];
+    dst[0] = s;
+    dst[1] = q;
   }
 }
 
@@ -117,9 +118,6 @@ int launch_gn_stats(const GroupNormArgs& a, hipStream_t s) {
   T2P_REQUIRE((a.C1 == 0) == (a.x1 == nullptr), "second source mismatch");
   const int nchunk = gn_num_chunks(a.HW);
   const int ncblk = (C + 1023) / 1024;
-  T2P_REQUIRE(ncblk == 1 || C % 1024 == 0 || (C - (ncblk - 1) * 1024) % 4 == 0, "channel blocking");
-  // a 1024-channel block must not split a source: C0 is either >= all blocks' range or aligned
-  T2P_REQUIRE(ncblk == 1 || a.C1 == 0 || a.C0 % 4 == 0, "concat alignment");
   dim3 grid(nchunk, a.B, ncblk);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, a, nchunk);
   const int tot = a.B * a.G;

@@ -1,0 +1,365 @@
+"""Predictor-corrector sampling on the HIP engine: mirror of ``score_sde_pytorch/sampling.py``.
+
+Same names, arguments, registries and error behaviour as the reference:
+
+  register_predictor / register_corrector / get_predictor / get_corrector   sampling.py:32-75
+      duplicate name -> ValueError, unknown name -> KeyError
+  get_sampling_fn(config, sde, shape, eps)                                  sampling.py:78-104
+  Predictor / Corrector ABCs, ReverseDiffusionPredictor, LangevinCorrector  sampling.py:107-199
+  get_pc_sampler(...) -> pc_sampler(model, condition=None, context=None)     sampling.py:213-291
+  get_score_fn(sde, model, train=False, continuous=False)                   models/utils.py:126-176
+
+The state update of every step (score network, noise, norms, Euler-Maruyama / Langevin update,
+conditional masking) runs in libt2p_hip.so.  torch is used for the once-per-run condition set-up
+and for (B,)-sized schedule scalars.  Two execution routes produce the same numbers:
+
+  * fused   -- VE SDE + 'reverse_diffusion' + 'langevin' + a ``HipScoreModel`` (every shipped
+               config): the whole step is enqueued by one C call (t2p_sampler_step), no host sync.
+  * classes -- anything else registered by the user, or the VP SDE: the loop below calls
+               ``update_fn`` of the predictor / corrector objects, which call the operator ABI.
+"""
+from __future__ import annotations
+
+import abc
+import ctypes as C
+import functools
+
+import torch
+
+from . import _lib, sde_lib
+from ._lib import SamplerConfig, T2PError, check, ptr, stream_ptr
+from .model import HipScoreModel
+
+_CORRECTORS = {}
+_PREDICTORS = {}
+
+
+def register_predictor(cls=None, *, name=None):
+    """A decorator for registering predictor classes."""
+
+    def _register(cls):
+        local_name = cls.__name__ if name is None else name
+        if local_name in _PREDICTORS:
+            raise ValueError(f"Already registered model with name: {local_name}")
+        _PREDICTORS[local_name] = cls
+        return cls
+
+    return _register if cls is None else _register(cls)
+
+
+def register_corrector(cls=None, *, name=None):
+    """A decorator for registering corrector classes."""
+
+    def _register(cls):
+        local_name = cls.__name__ if name is None else name
+        if local_name in _CORRECTORS:
+            raise ValueError(f"Already registered model with name: {local_name}")
+        _CORRECTORS[local_name] = cls
+        return cls
+
+    return _register if cls is None else _register(cls)
+
+
+def get_predictor(name):
+    return _PREDICTORS[name]
+
+
+def get_corrector(name):
+    return _CORRECTORS[name]
+
+
+# ------------------------------------------------------------------------------------------------
+# score function adapter
+# ------------------------------------------------------------------------------------------------
+def get_score_fn(sde, model, train=False, continuous=False):
+    """models/utils.py:126-176.  ``model`` is a ``HipScoreModel`` (or any callable with the
+    reference signature ``model(x, labels, context)``)."""
+    if train:
+        raise T2PError("the HIP engine is inference-only (train=True is not on the sampling path)")
+
+    def model_fn(x, labels, context=None):
+        model.eval()
+        return model(x, labels, context)
+
+    if isinstance(sde, (sde_lib.VPSDE, sde_lib.subVPSDE)):
+        def score_fn(x, t, context=None):
+            if continuous or isinstance(sde, sde_lib.subVPSDE):
+                labels = t * 999
+                score = model_fn(x, labels, context)
+                std = sde.marginal_prob_std(t)
+            else:
+                labels = t * (sde.N - 1)
+                score = model_fn(x, labels, context)
+                std = sde.sqrt_1m_alphas_cumprod.to(labels.device)[labels.long()]
+            return -score / std[:, None, None, None].to(score.device)
+    elif isinstance(sde, sde_lib.VESDE):
+        def score_fn(x, t, context=None):
+            if continuous:
+                labels = sde.marginal_prob_std(t)
+            else:
+                # For VE-trained models, t=0 corresponds to the highest noise level
+                labels = torch.round((sde.T - t) * (sde.N - 1)).long()
+            return model_fn(x, labels, context)
+    else:
+        raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+    return score_fn
+
+
+# ------------------------------------------------------------------------------------------------
+# predictors / correctors
+# ------------------------------------------------------------------------------------------------
+class Predictor(abc.ABC):
+    """The abstract class for a predictor algorithm."""
+
+    def __init__(self, sde, score_fn, probability_flow=False):
+        super().__init__()
+        self.sde = sde
+        self.score_fn = score_fn
+        self.probability_flow = probability_flow
+
+    @abc.abstractmethod
+    def update_fn(self, x, t, context=None):
+        """One update of the predictor -> (x, x_mean)."""
+
+
+class Corrector(abc.ABC):
+    """The abstract class for a corrector algorithm."""
+
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__()
+        self.sde = sde
+        self.score_fn = score_fn
+        self.snr = snr
+        self.n_steps = n_steps
+
+    @abc.abstractmethod
+    def update_fn(self, x, t, context=None):
+        """One update of the corrector -> (x, x_mean)."""
+
+
+def _device_randn_like(x, seed, stream_id):
+    out = torch.empty_like(x)
+    check(_lib.load().t2p_op_philox_normal(ptr(out), out.numel(), seed, stream_id, stream_ptr()))
+    return out
+
+
+class _NoiseSource:
+    """Standard-normal draws for the loop.  ``device``: Philox kernel keyed by (seed, draw index);
+    a callable ``noise_fn(shape) -> CPU tensor`` reproduces a host stream (parity runs)."""
+
+    def __init__(self, seed=0, noise_fn=None):
+        self.seed = int(seed)
+        self.noise_fn = noise_fn
+        self.count = 0
+
+    def like(self, x):
+        self.count += 1
+        if self.noise_fn is not None:
+            return self.noise_fn(tuple(x.shape)).to(x.device, torch.float32).contiguous()
+        return _device_randn_like(x, self.seed, self.count)
+
+
+_default_noise = _NoiseSource()
+
+
+@register_predictor(name="reverse_diffusion")
+class ReverseDiffusionPredictor(Predictor):
+    """sampling.py:157-167 with RSDE.discretize (sde_lib.py:96-101)."""
+
+    noise = _default_noise
+
+    def update_fn(self, x, t, context=None):
+        lib = _lib.load()
+        a, G = self.sde.discretize_coeffs(t)
+        score = self.score_fn(x, t, context).float().contiguous()
+        z = self.noise.like(x)
+        x_in = x
+        if float(a[0]) != 0.0:      # VP: f = (sqrt(alpha) - 1) x  ->  x - f = (2 - sqrt(alpha)) x
+            x_in = (x * (1.0 - a.to(x.device))[:, None, None, None]).contiguous()
+        x_new, x_mean = torch.empty_like(x), torch.empty_like(x)
+        check(lib.t2p_op_predictor(ptr(x_in), ptr(score), ptr(z), None, None, ptr(x_new), ptr(x_mean), x.numel(),
+                                   float(G[0]), int(bool(self.probability_flow)), stream_ptr()))
+        return x_new, x_mean
+
+
+@register_corrector(name="langevin")
+class LangevinCorrector(Corrector):
+    """sampling.py:170-199.  ``all_reduce`` (optional callable on the 2-float norm-sum tensor)
+    and ``global_batch`` give the global-batch step size of SURVEY 8(e) option B."""
+
+    noise = _default_noise
+    all_reduce = None
+    global_batch = None
+
+    def __init__(self, sde, score_fn, snr, n_steps):
+        super().__init__(sde, score_fn, snr, n_steps)
+        if not isinstance(sde, (sde_lib.VPSDE, sde_lib.VESDE, sde_lib.subVPSDE)):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+
+    def update_fn(self, x, t, context=None):
+        lib = _lib.load()
+        sde = self.sde
+        if isinstance(sde, (sde_lib.VPSDE, sde_lib.subVPSDE)):
+            timestep = (t.detach().cpu() * (sde.N - 1) / sde.T).long()
+            alpha = float(sde.alphas[timestep][0])
+        else:
+            alpha = 1.0
+        B = x.shape[0]
+        x_mean = x
+        ws = torch.empty(B * 128, device=x.device)
+        sums = torch.empty(2, device=x.device)
+        for _ in range(self.n_steps):
+            grad = self.score_fn(x, t, context).float().contiguous()
+            noise = self.noise.like(x)
+            check(lib.t2p_op_langevin_norms(ptr(grad), ptr(noise), B, x[0].numel(), ptr(ws), ptr(sums), stream_ptr()))
+            total = B
+            if self.all_reduce is not None:
+                self.all_reduce(sums)
+                total = self.global_batch or B
+            x_new, x_mean = torch.empty_like(x), torch.empty_like(x)
+            check(lib.t2p_op_langevin_update(ptr(x), ptr(grad), ptr(noise), None, None, ptr(x_new), ptr(x_mean),
+                                             x.numel(), ptr(sums), float(total), float(self.snr), alpha, stream_ptr()))
+            x = x_new
+        return x, x_mean
+
+
+def shared_predictor_update_fn(x, t, context, sde, model, predictor, probability_flow):
+    """A wrapper that configures and returns the update function of predictors (sampling.py:201-205)."""
+    score_fn = get_score_fn(sde, model, train=False)
+    return predictor(sde, score_fn, probability_flow).update_fn(x, t, context)
+
+
+def shared_corrector_update_fn(x, t, context, sde, model, corrector, snr, n_steps):
+    """sampling.py:207-211."""
+    score_fn = get_score_fn(sde, model, train=False)
+    return corrector(sde, score_fn, snr, n_steps).update_fn(x, t, context)
+
+
+# ------------------------------------------------------------------------------------------------
+# the sampler
+# ------------------------------------------------------------------------------------------------
+def get_sampling_fn(config, sde, shape, eps, **kw):
+    """sampling.py:78-104."""
+    predictor = get_predictor(config.sampling.predictor.lower())
+    corrector = get_corrector(config.sampling.corrector.lower())
+    return get_pc_sampler(sde=sde, shape=shape, predictor=predictor, corrector=corrector,
+                          snr=config.sampling.snr, n_steps=config.sampling.n_steps_each,
+                          probability_flow=config.sampling.probability_flow,
+                          denoise=config.sampling.noise_removal, eps=eps, device=config.device, **kw)
+
+
+def apply_conditions(x, condition):
+    """sampling.py:259-275: ``condition`` -> (x, conditional_mask).  One-off torch glue."""
+    mask = torch.ones_like(x).bool()
+    if condition is not None:
+        for k, v in condition.items():
+            if k == "length":
+                v = v.to(x.device)
+                x = x * v.unsqueeze(1)
+                mask = mask * v.unsqueeze(1)
+                x[:, -1] = v
+                mask[:, -1] = False
+            elif k == "ss":
+                x[:, 4:7] = v.to(x.device)
+                mask[:, 4:7] = False
+            elif k == "inpainting":
+                mask = mask * v["mask_inpaint"].to(x.device).unsqueeze(1)
+                x = torch.where(mask, x, v["coords_6d"].to(x.device))
+    return x, mask
+
+
+def get_pc_sampler(sde, shape, predictor, corrector, snr, n_steps=1, probability_flow=False, denoise=True,
+                   eps=1e-3, device="cuda", seed=0, force_classes=False):
+    """Create a Predictor-Corrector (PC) sampler (sampling.py:213-291).
+
+    Extra keyword arguments (not in the reference): ``seed`` of the on-device noise generator;
+    ``force_classes`` runs the predictor / corrector objects even where the fused route applies.
+    The returned ``pc_sampler(model, condition=None, context=None, noise_fn=None, n_iter=None)``
+    accepts ``noise_fn(shape) -> CPU tensor`` to inject the standard-normal draws in the
+    reference's order (prior, then corrector and predictor of each step), and ``n_iter`` to stop
+    after that many PC steps (benchmarks / tests).
+    """
+    device = torch.device("cuda:0" if str(device) == "cuda" else device)
+    if device.type != "cuda":
+        raise T2PError("the HIP sampler needs a GPU device (no CPU fallback)")
+    fused_ok = (isinstance(sde, sde_lib.VESDE) and predictor is ReverseDiffusionPredictor
+                and corrector is LangevinCorrector and not force_classes)
+    state = {"sampler": None, "model": None}
+
+    def _fused_sampler(model):
+        if state["sampler"] is not None and state["model"] is model:
+            return state["sampler"]
+        sc = SamplerConfig()
+        sc.sde = _lib.SDE_VE
+        sc.N = sde.N
+        sc.sigma_min, sc.sigma_max = float(sde.sigma_min), float(sde.sigma_max)
+        sc.beta_min, sc.beta_max = 0.1, 20.0
+        sc.snr = float(snr)
+        sc.n_steps_each = int(n_steps)
+        sc.probability_flow = int(bool(probability_flow))
+        sc.denoise = int(bool(denoise))
+        sc.eps = float(eps)
+        sc.batch = sc.global_batch = int(shape[0])
+        sc.seed = int(seed)
+        g = sde.g_table(eps)                       # the reference's own float32 arithmetic
+        h = C.c_void_p()
+        check(model.lib.t2p_sampler_create(model._h, C.byref(sc), C.c_void_p(g.data_ptr()), C.byref(h)))
+        state["sampler"], state["model"] = h, model
+        return h
+
+    def pc_sampler(model, condition=None, context=None, noise_fn=None, n_iter=None):
+        """The PC sampler function -> (samples, number of function evaluations)."""
+        lib = _lib.load()
+        torch.cuda.set_device(device)
+        n_iter = sde.N if n_iter is None else int(n_iter)
+        noise = _NoiseSource(seed, noise_fn)
+        with torch.no_grad():
+            # Initial sample (sde_lib.py:229-230): the reference draws on the CPU and moves it
+            if noise_fn is not None:
+                x = (noise_fn(tuple(shape)) * sde.prior_scale()).to(device, torch.float32)
+            else:
+                x = _device_randn_like(torch.empty(*shape, device=device), int(seed), 0) * sde.prior_scale()
+            x, conditional_mask = apply_conditions(x, condition)
+            x = x.float().contiguous()
+            x_initial = x.detach().clone()
+            conditioned = bool(condition)
+            mask_u8 = conditional_mask.to(torch.uint8).contiguous() if conditioned else None
+            if context is not None:
+                context = context.to(device, torch.float32).contiguous()
+                if isinstance(model, HipScoreModel):
+                    model.set_context(context)
+                    context = model._ctx_ref
+
+            if fused_ok and isinstance(model, HipScoreModel):
+                h = _fused_sampler(model)
+                check(lib.t2p_sampler_set_condition(h, ptr(mask_u8), ptr(x_initial) if conditioned else None))
+                check(lib.t2p_sampler_reset(h, 0, stream_ptr()))
+                x_mean = torch.empty_like(x)
+                for _ in range(n_iter):
+                    nc = npred = None
+                    if noise_fn is not None:
+                        nc, npred = noise.like(x), noise.like(x)
+                    check(lib.t2p_sampler_step(h, ptr(x), ptr(x_mean), ptr(nc), ptr(npred), stream_ptr()))
+            else:
+                ReverseDiffusionPredictor.noise = LangevinCorrector.noise = noise
+                timesteps = torch.linspace(sde.T, eps, sde.N, device=device)
+                predictor_update_fn = functools.partial(shared_predictor_update_fn, sde=sde, predictor=predictor,
+                                                        probability_flow=probability_flow)
+                corrector_update_fn = functools.partial(shared_corrector_update_fn, sde=sde, corrector=corrector,
+                                                        snr=snr, n_steps=n_steps)
+                x_mean = x
+                n_el = x.numel()
+                for i in range(n_iter):
+                    vec_t = torch.ones(shape[0], device=device) * timesteps[i]
+                    x, x_mean = corrector_update_fn(x, vec_t, model=model, context=context)
+                    if conditioned:
+                        check(lib.t2p_op_apply_mask(ptr(x), ptr(mask_u8), ptr(x_initial), n_el, stream_ptr()))
+                    x, x_mean = predictor_update_fn(x, vec_t, model=model, context=context)
+                    if conditioned:
+                        check(lib.t2p_op_apply_mask(ptr(x), ptr(mask_u8), ptr(x_initial), n_el, stream_ptr()))
+            if conditioned:
+                x_mean = x_mean.float().contiguous()
+                check(lib.t2p_op_apply_mask(ptr(x_mean), ptr(mask_u8), ptr(x_initial), x_mean.numel(), stream_ptr()))
+            return (x_mean if denoise else x), sde.N * (n_steps + 1)
+
+    return pc_sampler
