@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Benchmark of the reverse-diffusion sampling path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], SURVEY.md 8(d) "cfg2"): configs/test_config.yml with
+data.max_res_num = 128 and model.num_scales = 1000, 32 chains per GPU, 512 text tokens of width
+4096, synthetic non-degenerate weights (text2protein_amd/synth.py), unconditional sampling.
+
+A "step" is ONE predictor-corrector step over the batch: 2 score-network evaluations + Langevin
+corrector update + reverse-diffusion predictor update (reference sampling.py:279-285).  Every
+PC step has identical shapes and cost, and one sample is exactly `num_scales` = 1000 of them, so
+    samples/s = chains / (1000 * seconds_per_step).
+`--steps 1000` times a complete run.  Inputs (state, text keys/values, weights) are resident in
+HBM when the timed region starts; the per-run text K/V projection is loop-invariant and untimed.
+Chains shard over ranks with no per-step collective (per-GPU batches, SURVEY 8(e) option A); one
+RCCL all_gather of the final samples closes the timed region.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (config file, overrides, chains per GPU, text tokens, condition)
+    "cfg2": ("test_config.yml", {"data.max_res_num": 128, "model.num_scales": 1000}, 32, 512, None),
+    "cfg3": ("cond_length.yml", {"data.max_res_num": 128, "model.num_scales": 1000}, 32, 512, "length"),
+    "cfg4": ("test_config_large.yml", {"data.max_res_num": 256, "model.num_scales": 1000}, 16, 512, None),
+    "cfg5": ("cond_length_inpainting.yml", {"data.max_res_num": 128, "model.num_scales": 1000}, 16, 512, "length+inpainting"),
+}
+# algorithmic GFLOP per score evaluation per sample, K/V projections excluded
+ALG_GFLOP = {"cfg2": 645.3, "cfg3": 138.3, "cfg4": 2970.8, "cfg5": 138.5}
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}   # dense, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default=os.environ.get("T2P_BENCH_DTYPE", "f16"), choices=["f32", "bf16", "f16"])
+    ap.add_argument("--batch", type=int, default=None, help="chains per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, ctx_cpu, n_scales):
+    """The oracle (CPU restatement of the reference, checked against the reference's own runs)
+    timed on this box's host cores on a bounded sample of the same workload: 2 chains, 1 warm-up
+    score evaluation, then 1 PC step (2 evaluations); scaled by N PC steps per sample."""
+    from oracle import t2p_oracle as O
+    B = 2
+    C_, L = cfg.data.num_channels, cfg.data.max_res_num
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, C_, L, L, generator=g) * cfg.model.sigma_max
+    t = torch.ones(B)
+    with torch.no_grad():
+        O.score_fn_ve(sd, cfg, x, t, ctx_cpu[:B])          # warm-up (thread pools, allocator)
+        t0 = time.perf_counter()
+        O.pc_sampler_ve(sd, cfg, (B, C_, L, L), ctx_cpu[:B], noise_fn=lambda s: torch.randn(*s, generator=g),
+                        n_steps_limit=1)
+        dt = time.perf_counter() - t0
+    return {"value": B / (dt * n_scales), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{B} chains x 1 PC step (2 score evaluations) of the same workload on the host CPU "
+                      f"({os.cpu_count()} logical cores visible), scaled by {n_scales} PC steps per sample; "
+                      f"{dt:.2f} s measured"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+
+    from text2protein_amd import sampling, sde_lib, synth
+    from text2protein_amd._lib import check, load
+    from text2protein_amd.config import load_config
+    from text2protein_amd.model import HipScoreModel
+
+    fname, overrides, chains, T, cond_kind = WORKLOADS[args.workload]
+    B = args.batch or chains
+    cfg = load_config(os.path.join(ROOT, "configs", fname), **overrides)
+    cfg.device = str(dev)
+    N = cfg.model.num_scales
+    C_, L = cfg.data.num_channels, cfg.data.max_res_num
+
+    t_setup = time.perf_counter()
+    sd = synth.synth_state_dict(cfg, seed=0)                 # same weights on every rank (replicated model)
+    model = HipScoreModel(cfg, dtype=args.dtype, device=str(dev))
+    model.load_state_dict(sd)
+    ctx_cpu = synth.synth_context(B, T, cfg.model.context_dim, seed=1000 + rank)
+    ctx = ctx_cpu.to(dev)
+    model.set_context(ctx)                                   # one-off K/V projection of the frozen text
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=N)
+    stepper = sampling.PCStepper(model, sde, B, cfg.sampling.snr, cfg.sampling.n_steps_each,
+                                 cfg.sampling.probability_flow, cfg.sampling.noise_removal, 1e-5, seed=rank)
+    x = sampling._device_randn_like(torch.empty(B, C_, L, L, device=dev), 12345 + rank, 0) * sde.prior_scale()
+    if cond_kind:
+        from text2protein_amd.conditions import synthetic_condition
+        x, mask = sampling.apply_conditions(x, synthetic_condition(cfg, B, cond_kind, dev))
+        x = x.float().contiguous()
+        stepper.set_condition(mask.to(torch.uint8).contiguous(), x.clone())
+    x_mean = torch.empty_like(x)
+    stepper.reset(0)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        stepper.step(x, x_mean)
+    gathered = [torch.empty_like(x_mean) for _ in range(world)] if dist is not None else None
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper.step(x, x_mean)
+    if dist is not None:
+        dist.all_gather(gathered, x_mean)                    # the single collective of a run
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    finite = bool(torch.isfinite(x_mean).all().item())
+
+    ms_per_step = dt / args.steps * 1e3
+    total_chains = B * world
+    value = total_chains / (N * dt / args.steps)
+    alg = ALG_GFLOP[args.workload] * 1e9
+    out = {
+        "metric": "6D backbone samples/sec (128-res, 1000-step)" if L == 128 else f"6D backbone samples/sec ({L}-res, {N}-step)",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic (hash-generated non-degenerate weights, N(0,1) text embeddings, on-device Philox noise)",
+        "config": {"workload": f"{args.workload}: {fname} L={L} N={N} chains/GPU={B} C={C_} text_tokens={T} "
+                               f"condition={cond_kind or 'none'}; step = 1 PC step (2 score evals + SDE updates); "
+                               f"sample = {N} PC steps",
+                   "samples_per_min": value * 60.0, "setup_s": setup_s, "finite": finite,
+                   "mfma_frac_end_to_end": value * 2 * N * alg / world / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12),
+                   "device_gib": model.device_bytes() / 2 ** 30},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        lib = load()
+        check(lib.t2p_profile_begin())
+        nprof = 1
+        for _ in range(nprof):
+            stepper.step(x, x_mean)
+        o = (C.c_double * 6)()
+        check(lib.t2p_profile_end(o))
+        conv_ms, conv_fl, conv_n, g_ms, g_fl, g_n = list(o)
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        ach = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "gemm_kernel (implicit-GEMM 3x3 convolution launches)",
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "launches_per_step": conv_n / nprof, "avg_launch_ms": conv_ms / max(conv_n, 1),
+            "algorithmic_gflop_per_launch": conv_fl / max(conv_n, 1) / 1e9,
+            "share_of_step_ms": conv_ms / nprof,
+            "other_gemm": {"achieved": g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0, "launches_per_step": g_n / nprof,
+                           "share_of_step_ms": g_ms / nprof, "frac": (g_fl / (g_ms * 1e-3) / 1e12 / peak) if g_ms > 0 else 0.0},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, sd, ctx_cpu, N)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

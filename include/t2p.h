@@ -151,6 +151,11 @@ int t2p_op_convert(const float* in, void* out, int dtype, int64_t n, void* strea
 /* x = where(mask, x, x_initial) (sampling.py:283,285,287) */
 int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int64_t n, void* stream);
 
+/* ---- measurement hooks (bench.py): time every MFMA GEMM launch with HIP events on its stream ----
+ * out6 = {conv3x3: ms, flops, launches, other GEMMs: ms, flops, launches} since t2p_profile_begin */
+int t2p_profile_begin(void);
+int t2p_profile_end(double* out6);
+
 #ifdef __cplusplus
 }
 #endif

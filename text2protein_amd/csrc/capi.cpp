@@ -306,4 +306,20 @@ int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int
   API_END
 }
 
+int t2p_profile_begin(void) {
+  profile_begin();
+  return T2P_OK;
+}
+
+int t2p_profile_end(double* out6) {
+  API_BEGIN
+  T2P_REQUIRE(out6, "null argument");
+  double o[2][3];
+  T2P_TRY(profile_end(o));
+  for (int k = 0; k < 2; ++k)
+    for (int j = 0; j < 3; ++j) out6[k * 3 + j] = o[k][j];
+  return T2P_OK;
+  API_END
+}
+
 }  // extern "C"

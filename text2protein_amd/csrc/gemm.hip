@@ -14,6 +14,8 @@
 //   * bf16 / fp16  : v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulate
 // LDS rows hold BK = 128 bytes of K (32 fp32 / 64 16-bit elements); a lane's fragment for
 // k-group s is the 16 bytes at [row][32 s + 16 (lane >> 5)], for both element widths.
+#include <vector>
+
 #include "t2p_common.h"
 
 namespace t2p {
@@ -268,6 +270,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
+// ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream -----------
+struct ProfRec { hipEvent_t a, b; double flops; int kind; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+void profile_begin() {
+  for (ProfRec& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof.clear();
+  g_prof_on = true;
+}
+// out[kind][0..2] = {milliseconds, flops, launches}; kind 0 = 3x3 convolution, 1 = other GEMMs
+int profile_end(double out[2][3]) {
+  g_prof_on = false;
+  for (int k = 0; k < 2; ++k) out[k][0] = out[k][1] = out[k][2] = 0;
+  for (ProfRec& r : g_prof) {
+    T2P_HIP_CHECK(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    T2P_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+    out[r.kind][0] += ms; out[r.kind][1] += r.flops; out[r.kind][2] += 1;
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  return T2P_OK;
+}
+
 template <typename TC, bool AF32, int BM, int BN>
 static int launch_t(const GemmParams& p, hipStream_t stream) {
   constexpr int smem = 2 * (BM + BN) * ROWB;
@@ -278,7 +305,19 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     attr_set = true;
   }
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.nz0 * p.nz1);
+  ProfRec rec;
+  if (g_prof_on) {
+    T2P_HIP_CHECK(hipEventCreate(&rec.a));
+    T2P_HIP_CHECK(hipEventCreate(&rec.b));
+    rec.flops = 2.0 * p.M * p.N * (double)p.taps * (p.C0 + p.C1) * p.nz0 * p.nz1;
+    rec.kind = p.taps == 9 ? 0 : 1;
+    T2P_HIP_CHECK(hipEventRecord(rec.a, stream));
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
+  if (g_prof_on) {
+    T2P_HIP_CHECK(hipEventRecord(rec.b, stream));
+    g_prof.push_back(rec);
+  }
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }

@@ -119,5 +119,7 @@ struct GemmParams {
 };
 
 int launch_gemm(const GemmParams& p, hipStream_t stream);
+void profile_begin();
+int profile_end(double out[2][3]);
 
 }  // namespace t2p

@@ -238,6 +238,54 @@ def shared_corrector_update_fn(x, t, context, sde, model, corrector, snr, n_step
 # ------------------------------------------------------------------------------------------------
 # the sampler
 # ------------------------------------------------------------------------------------------------
+class PCStepper:
+    """Handle on the fused C++ sampler (t2p_sampler_*): one ``step`` = one iteration of the loop
+    body of the reference ``pc_sampler`` (sampling.py:279-285) enqueued on the current stream."""
+
+    def __init__(self, model, sde, batch, snr, n_steps=1, probability_flow=False, denoise=True, eps=1e-5, seed=0):
+        if not isinstance(sde, sde_lib.VESDE):
+            raise T2PError("the fused stepper covers the VE SDE; other SDEs run through the predictor/corrector classes")
+        if not isinstance(model, HipScoreModel):
+            raise T2PError("the fused stepper needs a HipScoreModel")
+        self.model, self.lib = model, model.lib
+        sc = SamplerConfig()
+        sc.sde = _lib.SDE_VE
+        sc.N = sde.N
+        sc.sigma_min, sc.sigma_max = float(sde.sigma_min), float(sde.sigma_max)
+        sc.beta_min, sc.beta_max = 0.1, 20.0
+        sc.snr = float(snr)
+        sc.n_steps_each = int(n_steps)
+        sc.probability_flow = int(bool(probability_flow))
+        sc.denoise = int(bool(denoise))
+        sc.eps = float(eps)
+        sc.batch = sc.global_batch = int(batch)
+        sc.seed = int(seed)
+        g = sde.g_table(eps)                       # the reference's own float32 arithmetic
+        h = C.c_void_p()
+        check(self.lib.t2p_sampler_create(model._h, C.byref(sc), C.c_void_p(g.data_ptr()), C.byref(h)))
+        self._h = h
+        self._keep = ()
+
+    def set_condition(self, mask_u8=None, x_initial=None):
+        self._keep = (mask_u8, x_initial)          # the C side borrows these pointers
+        check(self.lib.t2p_sampler_set_condition(self._h, ptr(mask_u8), ptr(x_initial)))
+
+    def reset(self, step=0):
+        check(self.lib.t2p_sampler_reset(self._h, int(step), stream_ptr()))
+
+    def step(self, x, x_mean, noise_corrector=None, noise_predictor=None):
+        check(self.lib.t2p_sampler_step(self._h, ptr(x), ptr(x_mean), ptr(noise_corrector), ptr(noise_predictor),
+                                        stream_ptr()))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.t2p_sampler_destroy(self._h)
+                self._h = None
+        except Exception:  # noqa: BLE001
+            pass
+
+
 def get_sampling_fn(config, sde, shape, eps, **kw):
     """sampling.py:78-104."""
     predictor = get_predictor(config.sampling.predictor.lower())
@@ -287,25 +335,10 @@ def get_pc_sampler(sde, shape, predictor, corrector, snr, n_steps=1, probability
     state = {"sampler": None, "model": None}
 
     def _fused_sampler(model):
-        if state["sampler"] is not None and state["model"] is model:
-            return state["sampler"]
-        sc = SamplerConfig()
-        sc.sde = _lib.SDE_VE
-        sc.N = sde.N
-        sc.sigma_min, sc.sigma_max = float(sde.sigma_min), float(sde.sigma_max)
-        sc.beta_min, sc.beta_max = 0.1, 20.0
-        sc.snr = float(snr)
-        sc.n_steps_each = int(n_steps)
-        sc.probability_flow = int(bool(probability_flow))
-        sc.denoise = int(bool(denoise))
-        sc.eps = float(eps)
-        sc.batch = sc.global_batch = int(shape[0])
-        sc.seed = int(seed)
-        g = sde.g_table(eps)                       # the reference's own float32 arithmetic
-        h = C.c_void_p()
-        check(model.lib.t2p_sampler_create(model._h, C.byref(sc), C.c_void_p(g.data_ptr()), C.byref(h)))
-        state["sampler"], state["model"] = h, model
-        return h
+        if state["sampler"] is None or state["model"] is not model:
+            state["sampler"] = PCStepper(model, sde, shape[0], snr, n_steps, probability_flow, denoise, eps, seed)
+            state["model"] = model
+        return state["sampler"]
 
     def pc_sampler(model, condition=None, context=None, noise_fn=None, n_iter=None):
         """The PC sampler function -> (samples, number of function evaluations)."""
@@ -331,15 +364,15 @@ def get_pc_sampler(sde, shape, predictor, corrector, snr, n_steps=1, probability
                     context = model._ctx_ref
 
             if fused_ok and isinstance(model, HipScoreModel):
-                h = _fused_sampler(model)
-                check(lib.t2p_sampler_set_condition(h, ptr(mask_u8), ptr(x_initial) if conditioned else None))
-                check(lib.t2p_sampler_reset(h, 0, stream_ptr()))
+                stepper = _fused_sampler(model)
+                stepper.set_condition(mask_u8, x_initial if conditioned else None)
+                stepper.reset(0)
                 x_mean = torch.empty_like(x)
                 for _ in range(n_iter):
                     nc = npred = None
                     if noise_fn is not None:
                         nc, npred = noise.like(x), noise.like(x)
-                    check(lib.t2p_sampler_step(h, ptr(x), ptr(x_mean), ptr(nc), ptr(npred), stream_ptr()))
+                    stepper.step(x, x_mean, nc, npred)
             else:
                 ReverseDiffusionPredictor.noise = LangevinCorrector.noise = noise
                 timesteps = torch.linspace(sde.T, eps, sde.N, device=device)
