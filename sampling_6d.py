@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""6D backbone sampling on MI355X: the reference's ``sampling_6d.py`` command line on the HIP engine.
+
+    python sampling_6d.py <config.yml> <checkpoint.pth> [--batch_size 32] [--tag test] [--device cuda]
+                          [--select_length True --length_index 61] [--mask_info 1:5,10:15] [--n_iter 1]
+
+Same positional arguments and flags as the reference (sampling_6d.py:41-53) and the same output
+contract (one pickle per sample, tensor (1, C, L, L), under
+sampling/coords_6d/<config stem>/<run>/<tag>/sampled_<id>.pkl, sampling_6d.py:160-162).
+Differences, all at the edges of the hot path:
+  * text context: the reference embeds captions with a LLaMA embedding table fetched by name
+    (sampling_6d.py:121-137); offline that producer is out of scope, so the context comes from
+    ``--context <file.pt>`` (a (B, T, context_dim) float tensor) or is synthetic (``--context synthetic``).
+  * ``--pdb`` conditions need biotite and are broken in the reference: refused.
+  * ``checkpoint`` may be the word ``synthetic`` (hash-generated weights, no file needed).
+  * extra flags: --dtype (f32|f16|bf16), --seed, --ids, --num_scales / --max_res_num overrides.
+Under ``python -m torch.distributed.run --nproc-per-node N`` every rank samples ``--batch_size``
+chains on its own GPU and rank 0 gathers them with one RCCL all_gather before writing.
+"""
+import argparse
+import os
+import pickle as pkl
+from pathlib import Path
+
+import torch
+
+
+def str2bool_like_reference(v):
+    # the reference declares type=bool, so any non-empty string is True (sampling_6d.py:51)
+    return bool(v)
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("config", type=str)
+    parser.add_argument("checkpoint", type=str)
+    parser.add_argument("--pdb", type=str, default=None)
+    parser.add_argument("--chain", type=str, default="A")
+    parser.add_argument("--mask_info", type=str, default="1:5,10:15")
+    parser.add_argument("--tag", type=str, default="test")
+    parser.add_argument("--device", type=str, default="cuda")
+    parser.add_argument("--batch_size", type=int, default=32)
+    parser.add_argument("--n_iter", type=int, default=1)
+    parser.add_argument("--select_length", type=str2bool_like_reference, default=False)
+    parser.add_argument("--length_index", type=int, default=1)  # Index starts at 1
+    # additions
+    parser.add_argument("--dtype", type=str, default="f16", choices=["f32", "f16", "bf16"])
+    parser.add_argument("--context", type=str, default="synthetic")
+    parser.add_argument("--context_tokens", type=int, default=512)
+    parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--ids", type=str, default=None, help="comma separated sample ids (default 0..B-1)")
+    parser.add_argument("--num_scales", type=int, default=None)
+    parser.add_argument("--max_res_num", type=int, default=None)
+    parser.add_argument("--outdir", type=str, default=None)
+    args = parser.parse_args()
+
+    assert not (args.pdb is not None and args.select_length)
+    if args.pdb is not None:
+        raise SystemExit("--pdb conditions are outside the sampling hot path (need biotite; see SURVEY.md section 2, row 10)")
+
+    from text2protein_amd import sampling, sde_lib, synth
+    from text2protein_amd.checkpoint import restore_checkpoint
+    from text2protein_amd.conditions import get_mask_all_lengths
+    from text2protein_amd.config import load_config
+    from text2protein_amd.model import HipScoreModel
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    overrides = {}
+    if args.num_scales:
+        overrides["model.num_scales"] = args.num_scales
+    if args.max_res_num:
+        overrides["data.max_res_num"] = args.max_res_num
+    config = load_config(args.config, **overrides)
+    device = f"cuda:{local_rank}" if args.device == "cuda" else args.device
+    config.device = device
+    torch.cuda.set_device(torch.device(device))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+
+    run = Path(args.checkpoint).parent.parent.stem if args.checkpoint != "synthetic" else "synthetic"
+    workdir = Path(args.outdir) if args.outdir else Path("sampling", "coords_6d", Path(args.config).stem, run, args.tag)
+    if rank == 0:
+        workdir.mkdir(parents=True, exist_ok=True)
+
+    # Initialize model (get_model + restore_checkpoint + ema.copy_to, sampling_6d.py:64-73)
+    score_model = HipScoreModel(config, dtype=args.dtype, device=device)
+    if args.checkpoint == "synthetic":
+        score_model.load_state_dict(synth.synth_state_dict(config, args.seed))
+    else:
+        restore_checkpoint(args.checkpoint, score_model, config)
+
+    # Load SDE (sampling_6d.py:76-82)
+    if config.training.sde == "vesde":
+        sde = sde_lib.VESDE(sigma_min=config.model.sigma_min, sigma_max=config.model.sigma_max, N=config.model.num_scales)
+        sampling_eps = 1e-5
+    elif config.training.sde == "vpsde":
+        sde = sde_lib.VPSDE(beta_min=config.model.beta_min, beta_max=config.model.beta_max, N=config.model.num_scales)
+        sampling_eps = 1e-3
+    else:
+        raise SystemExit(f"unknown training.sde {config.training.sde}")
+
+    B = args.batch_size
+    sampling_shape = (B, config.data.num_channels, config.data.max_res_num, config.data.max_res_num)
+    sampling_fn = sampling.get_sampling_fn(config, sde, sampling_shape, sampling_eps, seed=args.seed * 1000 + rank)
+
+    if args.context == "synthetic":
+        context = synth.synth_context(B, args.context_tokens, config.model.context_dim, seed=args.seed * 1000 + rank)
+    else:
+        context = torch.load(args.context, map_location="cpu")
+        if context.shape[0] != B:
+            raise SystemExit(f"context batch {context.shape[0]} != --batch_size {B}")
+    ids = args.ids.split(",") if args.ids else [str(rank * B + i) for i in range(B)]
+    if len(ids) != B:
+        raise SystemExit("--ids must list batch_size ids")
+
+    for it in range(args.n_iter):
+        if args.select_length:
+            mask = get_mask_all_lengths(config, batch_size=B)[args.length_index - 1]
+            condition = {"length": mask.to(device)}
+        else:
+            condition = {}
+        sample, n = sampling_fn(score_model, condition=condition, context=context)
+        if dist is not None:
+            parts = [torch.empty_like(sample) for _ in range(world)]
+            dist.all_gather(parts, sample.contiguous())
+            all_ids = [None] * world
+            dist.all_gather_object(all_ids, ids)
+            sample = torch.cat(parts, 0)
+            out_ids = [i for sub in all_ids for i in sub]
+        else:
+            out_ids = ids
+        generated = sample.cpu()
+        if rank == 0:
+            print("show generated samples shape: ", generated.shape)
+            for i, sid in enumerate(out_ids):
+                suffix = f"_{it}" if args.n_iter > 1 else ""
+                with open(workdir.joinpath(f"sampled_{sid}{suffix}.pkl"), "wb") as f:
+                    pkl.dump(generated[i].unsqueeze(0), f)
+            print(f"[{it + 1} / {args.n_iter}] save samples to {workdir} ({n} score evaluations per chain)")
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+"""CPU-side checks: config surface, structure tables, synthetic data, host logic, and that the
+C-ABI library loads and exports every symbol include/t2p.h declares (no compute without a GPU)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import cfg_tiny
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_configs_load_and_param_counts():
+    from text2protein_amd.arch import build_arch, param_specs
+    from text2protein_amd.config import load_config
+    n = {}
+    for name, over in [("test_config.yml", {"data.max_res_num": 128}), ("test_config.yml", {"data.max_res_num": 64}),
+                       ("cond_length.yml", {}), ("test_config_large.yml", {}), ("cond_length_inpainting.yml", {})]:
+        cfg = load_config(os.path.join(ROOT, "configs", name), **over)
+        assert cfg.model.n_heads == 8 and cfg.model.context_dim == 4096    # defaults supplied
+        specs = param_specs(cfg)
+        n[(name, cfg.data.max_res_num)] = sum(int(np.prod(s.shape)) for s in specs)
+        a = build_arch(cfg)
+        assert len(a.input_stages) == len(cfg.model.ch_mult) * cfg.model.num_res_blocks + len(cfg.model.ch_mult) - 1
+    # parameter counts probed from the reference model
+    assert round(n[("test_config.yml", 128)] / 1e6, 1) == 379.5
+    assert round(n[("test_config.yml", 64)] / 1e6, 1) == 345.4
+    assert round(n[("cond_length.yml", 128)] / 1e6, 1) == 75.0
+    assert round(n[("test_config_large.yml", 256)] / 1e6, 1) == 863.3
+
+
+def test_attrdict_behaviour():
+    from text2protein_amd.config import AttrDict, finalize_config
+    c = AttrDict({"a": {"b": 1}, "l": [{"x": 2}]})
+    assert c.a.b == 1 and c["a"]["b"] == 1 and c.l[0].x == 2
+    c.a.b = 5
+    assert c["a"]["b"] == 5
+    with pytest.raises(AttributeError):
+        c.missing
+    cfg = finalize_config({"model": {"condition": None}, "data": {}}, **{"data.max_res_num": 7})
+    assert cfg.model.condition == [] and cfg.data.max_res_num == 7 and cfg.model.n_heads == 8
+
+
+def test_synth_is_deterministic_and_non_degenerate():
+    from text2protein_amd import synth
+    from text2protein_amd.arch import param_specs
+    cfg = cfg_tiny()
+    a = synth.synth_state_dict(cfg, 3)
+    b = synth.synth_state_dict(cfg, 3)
+    c = synth.synth_state_dict(cfg, 4)
+    for s in param_specs(cfg):
+        assert torch.equal(a[s.name], b[s.name])
+        assert float(a[s.name].abs().max()) > 1e-4, s.name       # nothing zero / 1e-10 scaled
+    assert not torch.equal(a["pre_conv.weight"], c["pre_conv.weight"])
+    w = a["mid_blocks.0.Conv_0.weight"]
+    assert abs(float(w.var()) * w[0].numel() - 1.0) < 0.15       # variance 1 / fan_in
+    z = synth.normal(0, "z", 200000)
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1) < 0.01
+    # chunked generation equals one-shot generation
+    assert np.array_equal(synth.uniform_pm1(1, "t", 1000, chunk=64), synth.uniform_pm1(1, "t", 1000))
+
+
+def test_condition_builders_match_oracle():
+    from oracle import t2p_oracle as O
+    from text2protein_amd import conditions
+    cfg = cfg_tiny()
+    m = conditions.get_mask_all_lengths(cfg, batch_size=3)
+    assert torch.equal(m, O.mask_all_lengths(cfg.data.min_res_num, cfg.data.max_res_num, 3))
+    cfg.model.condition = ["inpainting"]
+    batch = conditions.selected_mask_batch({"coords_6d": torch.zeros(2, 5, 16, 16)}, "1:3,6,9:10", cfg)
+    assert torch.equal(batch["mask_inpaint"], O.selected_mask("1:3,6,9:10", 2, 16))
+    cfg.model.condition = []
+    assert conditions.selected_mask_batch({"coords_6d": torch.zeros(2, 5, 16, 16)}, "1:3", cfg)["mask_inpaint"] is None
+
+
+def test_apply_conditions_matches_oracle():
+    from oracle import t2p_oracle as O
+    from text2protein_amd import sampling
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 8, 16, 16, generator=g)
+    cond = {"length": O.mask_all_lengths(4, 16, 2)[7], "ss": torch.randn(2, 3, 16, 16, generator=g),
+            "inpainting": {"coords_6d": torch.rand(2, 8, 16, 16, generator=g), "mask_inpaint": O.selected_mask("1:5", 2, 16)}}
+    a, am = sampling.apply_conditions(x.clone(), cond)
+    b, bm = O.apply_conditions(x.clone(), cond)
+    assert torch.equal(a, b) and torch.equal(am, bm)
+
+
+def test_sde_tables_match_golden():
+    from helpers import load_golden
+    from text2protein_amd import sde_lib
+    g = load_golden("tables")
+    for N in (100, 1000, 2000):
+        sde = sde_lib.VESDE(0.01, 100.0, N)
+        assert np.array_equal(sde.discrete_sigmas.numpy(), g[f"discrete_sigmas_{N}"])
+        assert np.array_equal(sde.g_table(1e-5).numpy(), g[f"G_{N}"])
+        vp = sde_lib.VPSDE(0.1, 20.0, N)
+        assert np.array_equal(vp.alphas.numpy(), g[f"vp_alphas_{N}"])
+        assert np.array_equal(vp.sqrt_1m_alphas_cumprod.numpy(), g[f"vp_sqrt_1m_acp_{N}"])
+
+
+def test_registries_and_errors():
+    from text2protein_amd import sampling, sde_lib
+    assert sampling.get_predictor("reverse_diffusion") is sampling.ReverseDiffusionPredictor
+    with pytest.raises(KeyError):
+        sampling.get_predictor("euler_maruyama")
+    with pytest.raises(ValueError):
+        sampling.register_corrector(name="langevin")(sampling.LangevinCorrector)
+
+    class Other:
+        pass
+
+    with pytest.raises(NotImplementedError):
+        sampling.get_score_fn(Other(), lambda *a: None)
+    with pytest.raises(NotImplementedError):
+        sampling.LangevinCorrector(Other(), None, 0.1, 1)
+    assert sde_lib.VESDE(0.01, 100, 10).T == 1
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    from text2protein_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "t2p.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(t2p_[a-z0-9_]+)\s*\(", hdr))
+    assert declared and declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a GPU the product path refuses to run: there is no CPU fallback."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import ctypes as C
+    from text2protein_amd import _lib
+    from text2protein_amd.model import HipScoreModel, _model_config
+    lib = _lib.load()
+    assert lib.t2p_device_count() <= 0
+    h = C.c_void_p()
+    mc = _model_config(cfg_tiny(), "f32")
+    assert lib.t2p_engine_create(C.byref(mc), C.byref(h)) != 0
+    assert b"no HIP device" in lib.t2p_last_error()
+    with pytest.raises(Exception):
+        HipScoreModel(cfg_tiny(), device="cuda:0")
+    with pytest.raises(_lib.T2PError):
+        HipScoreModel(cfg_tiny(), device="cpu")
+
+
+def test_product_path_does_not_import_the_oracle():
+    import ast
+    pkg = os.path.join(ROOT, "text2protein_amd")
+    for fn in list(os.listdir(pkg)) + ["../sampling_6d.py"]:
+        if not fn.endswith(".py"):
+            continue
+        tree = ast.parse(open(os.path.join(pkg, fn)).read())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n.split(".")[0] == "oracle" for n in names), fn
+
+
+def test_checkpoint_roundtrip_layout(tmp_path):
+    from text2protein_amd import checkpoint, synth
+    cfg = cfg_tiny()
+    p = checkpoint.save_synthetic_checkpoint(str(tmp_path / "ckpt.pth"), cfg, seed=2)
+    st = torch.load(p, weights_only=False)
+    assert set(st) == {"optimizer", "model", "ema", "step"}
+    assert all(k.startswith("module.") for k in st["model"])
+    assert st["model"]["module.sigmas"].dtype == torch.float64
+    sd = checkpoint.ema_state_dict(cfg, st)
+    ref = synth.synth_state_dict(cfg, 2)
+    assert list(sd) == list(ref) and all(torch.equal(sd[k], ref[k]) for k in ref)
+    assert checkpoint.strip_module_prefix(st["model"]).keys() >= ref.keys()

@@ -1,0 +1,59 @@
+"""Checkpoint side of the sampling driver: reference ``score_sde_pytorch/utils.py:11-26`` and
+``score_sde_pytorch/models/ema.py:51-93``, load side only.
+
+A reference checkpoint is ``torch.save({'optimizer', 'model', 'ema', 'step'})`` where ``model`` is a
+DataParallel state dict (every key prefixed ``module.``, plus the float64 buffer
+``module.sigmas``) and ``ema`` is ``{'decay', 'num_updates', 'shadow_params'}`` with
+``shadow_params`` a list of tensors in ``model.parameters()`` order.  The driver restores the
+model and then overwrites the live parameters with the EMA ones (sampling_6d.py:71-73); the HIP
+engine is immutable once finalized, so ``restore_checkpoint`` loads the EMA weights directly.
+"""
+from __future__ import annotations
+
+import torch
+
+from .arch import param_specs
+from ._lib import T2PError
+
+
+def strip_module_prefix(state_dict):
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+
+
+def ema_state_dict(config, loaded_state):
+    """What ``ema.copy_to(model.parameters())`` leaves in the model, as a name -> tensor dict."""
+    specs = param_specs(config)
+    shadow = loaded_state["ema"]["shadow_params"]
+    if len(shadow) != len(specs):
+        raise T2PError(f"checkpoint EMA has {len(shadow)} tensors, the model for this config has {len(specs)}")
+    out = {}
+    for s, p in zip(specs, shadow):
+        if tuple(p.shape) != tuple(s.shape):
+            raise T2PError(f"EMA tensor for {s.name} has shape {tuple(p.shape)}, expected {tuple(s.shape)}")
+        out[s.name] = p
+    return out
+
+
+def restore_checkpoint(ckpt_path, model, config, device="cpu", use_ema=True):
+    """Load a reference ``.pth`` into a ``HipScoreModel``; returns the checkpoint's ``step``."""
+    loaded = torch.load(ckpt_path, map_location=device, weights_only=False)
+    if use_ema and "ema" in loaded and loaded["ema"].get("shadow_params"):
+        sd = ema_state_dict(config, loaded)
+    else:
+        sd = strip_module_prefix(loaded["model"])
+    model.load_state_dict(sd)
+    return loaded.get("step", 0)
+
+
+def save_synthetic_checkpoint(path, config, seed=0):
+    """Write a checkpoint in the reference's layout from the synthetic weights (tests, demos)."""
+    from . import synth
+    sd = synth.synth_state_dict(config, seed)
+    specs = param_specs(config)
+    model_sd = {"module." + k: v for k, v in sd.items()}
+    model_sd["module.sigmas"] = torch.tensor(__import__("text2protein_amd.model", fromlist=["x"]).get_sigmas(config))
+    state = {"optimizer": {}, "model": model_sd,
+             "ema": {"decay": config.model.ema_rate, "num_updates": 0, "shadow_params": [sd[s.name] for s in specs]},
+             "step": 0}
+    torch.save(state, path)
+    return path
