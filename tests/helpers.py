@@ -27,3 +27,10 @@ def rel_l2(a, b):
     a = torch.as_tensor(a).double()
     b = torch.as_tensor(b).double()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def cfg_smallC():
+    """Wide enough (64/128 channels, 32x32 maps) for the LDS-DMA GEMM kernel to be selected."""
+    return tiny_config(**{"model.nf": 64, "model.ch_mult": [1, 2], "model.num_res_blocks": 1, "data.max_res_num": 32,
+                          "model.attn_resolutions": [16], "model.n_heads": 4, "model.context_dim": 64,
+                          "model.num_scales": 10})

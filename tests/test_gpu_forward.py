@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_golden, cfg_tiny, cfg_tinyB, rel_l2
+from helpers import load_golden, cfg_tiny, cfg_tinyB, cfg_smallC, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -53,3 +53,24 @@ def test_missing_weight_fails_loudly():
         m.load_state_dict(sd)
     with pytest.raises(T2PError):
         m(torch.zeros(1, 5, 16, 16).cuda(), torch.zeros(1).long().cuda(), torch.zeros(1, 3, 32).cuda())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+def test_score_wide_config_matches_oracle(dtype):
+    """64/128-channel maps at 32x32: the configuration where the LDS-DMA kernel carries the convolutions."""
+    from oracle import t2p_oracle as O
+    from text2protein_amd import synth
+    cfg = cfg_smallC()
+    sd = synth.synth_state_dict(cfg, 11)
+    B, T = 3, 20
+    x = torch.from_numpy(synth.normal(11, "x", B * 5 * 32 * 32).reshape(B, 5, 32, 32)) * 20.0
+    ctx = synth.synth_context(B, T, cfg.model.context_dim, 11)
+    labels = torch.tensor([0, 4, 9])
+    with torch.no_grad():
+        want = O.unet_forward(sd, cfg, x, labels, ctx)
+    m = make_model(cfg, 11, dtype)
+    got = m(x.cuda(), labels.cuda(), ctx.cuda())
+    torch.cuda.synchronize()
+    err = rel_l2(got.cpu(), want)
+    print(f"wide config {dtype}: score rel-L2 vs oracle = {err:.3e}")
+    assert err < SCORE_TOL[dtype]

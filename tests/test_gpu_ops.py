@@ -46,7 +46,8 @@ def check(lib, rc):
 
 
 @pytest.mark.parametrize("dt", [0, 1, 2])
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 72, 40), (1000, 515, 264), (64, 5, 32), (7, 130, 8)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 72, 40), (1000, 515, 264), (64, 5, 32), (7, 130, 8),
+                                   (512, 256, 128), (1000, 130, 192), (4096, 512, 1024), (300, 64, 72)])
 def test_gemm(lib, dt, M, N, K):
     g = torch.Generator().manual_seed(M * 7 + N)
     a = torch.randn(M, K, generator=g)
@@ -69,7 +70,10 @@ def test_gemm(lib, dt, M, N, K):
 
 @pytest.mark.parametrize("dt", [0, 1, 2])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,up", [(2, 16, 16, 32, 64, 0), (1, 8, 12, 96, 32, 0), (2, 8, 8, 64, 40, 1),
-                                              (3, 4, 4, 8, 5, 0), (1, 32, 32, 264, 136, 0)])
+                                              (3, 4, 4, 8, 5, 0), (1, 32, 32, 264, 136, 0),
+                                              # shapes that take the LDS-DMA kernel (16-bit, Cin % 64 == 0, M >= 256)
+                                              (2, 32, 32, 64, 128, 0), (1, 16, 16, 128, 64, 1), (2, 16, 24, 192, 72, 0),
+                                              (3, 20, 12, 256, 256, 0), (1, 64, 64, 64, 200, 1)])
 def test_conv3x3(lib, dt, B, H, W, Cin, Cout, up):
     g = torch.Generator().manual_seed(H * 31 + Cin)
     hs, ws = (H // 2, W // 2) if up else (H, W)
@@ -84,6 +88,14 @@ def test_conv3x3(lib, dt, B, H, W, Cin, Cout, up):
     check(lib, lib.t2p_op_conv3x3(dt, P(dx), 1, P(dw), P(dev(b)), P(out), B, H, W, Cin, Cout, up, None))
     torch.cuda.synchronize()
     assert rel_l2(out.cpu(), ref) < TOL[dt]
+    if dt:   # activations already in the compute dtype (what the engine feeds): LDS-DMA kernel where eligible
+        x16 = x.to(TDT[dt])
+        xin16 = x16.repeat_interleave(2, 2).repeat_interleave(2, 3) if up else x16
+        ref16 = F.conv2d(xin16.double(), w.to(TDT[dt]).double(), b.double(), padding=1).permute(0, 2, 3, 1)
+        out2 = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+        check(lib, lib.t2p_op_conv3x3(dt, P(dev(x16.permute(0, 2, 3, 1))), 0, P(dw), P(dev(b)), P(out2), B, H, W, Cin, Cout, up, None))
+        torch.cuda.synchronize()
+        assert rel_l2(out2.cpu(), ref16) < 3e-6      # same rounded operands, fp32 accumulation
 
 
 @pytest.mark.parametrize("C0,C1,G,silu,down", [(32, 0, 8, 1, 0), (64, 32, 24, 1, 0), (512, 256, 32, 0, 0),

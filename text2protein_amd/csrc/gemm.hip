@@ -270,6 +270,257 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
+// =================================================================================================
+// v2: LDS-DMA pipeline for 16-bit operands (the dominant kernel: 3x3 convolutions and large GEMMs).
+//
+// v1 above stages operands through registers; its ds_write_b128 traffic (~79 B/clk/CU) plus the
+// fragment reads make it LDS-bound at about 15 % of the 16-bit MFMA peak.  Here both operand
+// tiles go HBM/L2 -> LDS directly with `buffer_load_dwordx4 ... lds` (no VGPR round trip, no
+// ds_write), which also gives the convolution's zero padding and all ragged edges for free: a
+// lane whose source is outside the map / matrix gets an out-of-range buffer offset and the
+// hardware writes zeros.
+//   * workgroup = 8 wavefronts (4 x 2), tile BM x BN = 256 x 128, BK = 64 (128-byte LDS rows)
+//   * LDS ring of 3 stages (3 x 48 KiB); the loads of K-tile t+2 are issued while tile t is being
+//     multiplied; a counted `s_waitcnt vmcnt(6)` + one raw s_barrier per K-tile
+//   * LDS image is lane-linear per DMA instruction (8 rows x 128 B), so the bank-conflict swizzle
+//     is applied to the SOURCE chunk: position p of row r holds chunk p ^ ((r >> 1) & 7), and the
+//     ds_read_b128 fragment reads apply the same XOR (conflict-free for all 16-lane groups)
+//   * tile ids are remapped so that consecutive tiles (same A rows, neighbouring pixels) run on
+//     the same XCD and share its L2
+// Requirements (else v1 runs): 16-bit compute dtype, A in the compute dtype, C0 % 64 == 0,
+// (C0 + C1) % 8 == 0, every operand smaller than 2 GiB.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#define T2P_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+static constexpr unsigned DMA_OOB = 0x80000000u;   // >= any num_records we accept -> zeros
+
+template <typename TC, int BM, int BN>
+__global__ __launch_bounds__(512) void gemm_dma_kernel(const GemmParams p, const int tiles_m, const int tiles_n) {
+  constexpr int BK = 64;
+  constexpr int NST = 3;
+  constexpr int WM = BM / 64, WN = BN / 64;           // wave grid (4 x 2)
+  static_assert(WM * WN == 8, "8 wavefronts");
+  constexpr int A_INSTR = BM / 64, B_INSTR = BN / 64;  // DMA instructions per wave per K-tile (8 rows each)
+  constexpr int STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // XCD-aware tile order: blocks b and b + 8 share an XCD; give each XCD a contiguous tile range
+  const int ntiles = tiles_m * tiles_n;
+  int tile = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z0 = blockIdx.y / p.nz1, z1 = blockIdx.y % p.nz1;
+
+  const int Ctot = p.C0 + p.C1;
+  const int nch = (Ctot + BK - 1) / BK;
+  const int nk = nch * p.taps;
+  const bool spatial = (p.taps == 9) || p.a_up;
+  const int HW = p.H * p.W;
+  const int Hs = p.a_up ? (p.H >> 1) : p.H, Ws = p.a_up ? (p.W >> 1) : p.W;
+
+  // buffer descriptors: whole operand in range, everything else reads as zero.  Built from
+  // readfirstlane'd scalars so that hipcc keeps them in SGPRs (no waterfall loop around the DMA).
+  auto make_rsrc = [](const void* base, int bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const int nb = __builtin_amdgcn_readfirstlane(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
+  };
+  const long a_rows = spatial ? (long)(p.M / HW) * Hs * Ws : (long)p.M;
+  const TC* A0p = (const TC*)p.A0 + (long)z0 * p.sA_z0 + (long)z1 * p.sA_z1;
+  const TC* Bp = (const TC*)p.Bw + (long)z0 * p.sB_z0 + (long)z1 * p.sB_z1;
+  const int a0_bytes = (int)(((a_rows - 1) * p.lda0 + p.C0) * 2);
+  const int a1_bytes = p.A1 ? (int)(((a_rows - 1) * p.lda1 + p.C1) * 2) : 0;
+  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bp, (int)((((long)p.N - 1) * p.ldb + (long)p.taps * Ctot) * 2));
+
+  // per-lane DMA geometry: instruction j of this wave covers tile rows (wave * INSTR + j) * 8 + (lane >> 3)
+  const int prow = lane >> 3, ppos = lane & 7;
+  int a_b[A_INSTR], a_y[A_INSTR], a_x[A_INSTR];
+  unsigned a_chunk[A_INSTR];     // byte offset of this lane's (swizzled) source chunk inside the 128-byte K-slice
+  bool a_ok[A_INSTR];
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int r = (wave * A_INSTR + j) * 8 + prow;
+    const int m = m0 + r;
+    a_ok[j] = m < p.M;
+    a_chunk[j] = (unsigned)((ppos ^ ((r >> 1) & 7)) * 16);
+    if (spatial) {
+      const int b = m / HW, rem = m - b * HW;
+      a_b[j] = b; a_y[j] = rem / p.W; a_x[j] = rem - a_y[j] * p.W;
+    } else {
+      a_b[j] = m; a_y[j] = 0; a_x[j] = 0;
+    }
+  }
+  unsigned b_off[B_INSTR], b_chunk[B_INSTR];
+  bool b_ok[B_INSTR];
+#pragma unroll
+  for (int j = 0; j < B_INSTR; ++j) {
+    const int r = (wave * B_INSTR + j) * 8 + prow;
+    const int n = n0 + r;
+    b_ok[j] = n < p.N;
+    b_off[j] = (unsigned)((long)n * p.ldb * 2);
+    b_chunk[j] = (unsigned)((ppos ^ ((r >> 1) & 7)) * 16);
+  }
+
+  // source pixel row of each DMA row for the current tap (-1: outside the map / beyond M);
+  // recomputed only when the tap changes (every nch K-tiles)
+  int a_src[A_INSTR];
+  auto set_tap = [&](int tap) {
+    int dy = 0, dx = 0;
+    if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      int row = a_b[j];
+      bool ok = a_ok[j];
+      if (spatial) {
+        int sy = a_y[j] + dy, sx = a_x[j] + dx;
+        ok = ok && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+        if (p.a_up) { sy >>= 1; sx >>= 1; }
+        row = (a_b[j] * Hs + sy) * Ws + sx;
+      }
+      a_src[j] = ok ? row : -1;
+    }
+  };
+
+  auto issue = [&](int kt) {
+    unsigned char* st = smem + (kt % NST) * STAGE;
+    const int tap = kt / nch;
+    const int c0 = (kt - tap * nch) * BK;              // channel base of this K-tile
+    if (c0 == 0) set_tap(tap);
+    const bool second = c0 >= p.C0;                    // wave-uniform: C0 % 64 == 0
+    const int csrc = second ? c0 - p.C0 : c0;
+    const int cend = second ? p.C1 : p.C0;             // channels available in this source
+    const unsigned ld2 = (unsigned)((second ? p.lda1 : p.lda0) * 2);
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(second ? (const void*)p.A1 : (const void*)A0p, second ? a1_bytes : a0_bytes);
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      const bool ok = a_src[j] >= 0 && (csrc + (int)(a_chunk[j] >> 1) < cend);
+      const unsigned voff = ok ? (unsigned)a_src[j] * ld2 + (unsigned)(csrc * 2) + a_chunk[j] : DMA_OOB;
+      unsigned char* dst = st + (wave * A_INSTR + j) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, T2P_LDS_PTR(dst), 16, voff, 0, 0, 0);
+    }
+    const unsigned kb = (unsigned)(((long)tap * Ctot + c0) * 2);
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+      const bool ok = b_ok[j] && (c0 + (int)(b_chunk[j] >> 1) < Ctot);
+      const unsigned voff = ok ? b_off[j] + kb + b_chunk[j] : DMA_OOB;
+      unsigned char* dst = st + BM * 128 + (wave * B_INSTR + j) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, T2P_LDS_PTR(dst), 16, voff, 0, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  // fragment read offsets: row (wm*64 + i*32 + lr), chunk (2 s + lh) ^ ((row >> 1) & 7)
+  unsigned a_fo[2][4], b_fo[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra = wm * 64 + i * 32 + lr, rb = wn * 64 + i * 32 + lr;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      a_fo[i][s] = (unsigned)(ra * 128 + (((2 * s + lh) ^ ((ra >> 1) & 7)) << 4));
+      b_fo[i][s] = (unsigned)(BM * 128 + rb * 128 + (((2 * s + lh) ^ ((rb >> 1) & 7)) << 4));
+    }
+  }
+
+  const unsigned lds_base = (unsigned)(unsigned long long)T2P_LDS_PTR(smem);
+  issue(0);
+  if (nk > 1) issue(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + B_INSTR) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(kt + 2);
+    // Fragment reads go through inline asm: hipcc would otherwise put `s_waitcnt vmcnt(0)` in
+    // front of every ds_read that may alias an in-flight LDS-DMA write and drain the ring.  The
+    // reads of k-step s+1 are in flight while the MFMAs of step s run (lgkmcnt counts LDS ops in
+    // order: <= 4 outstanding means step s has landed).
+    const unsigned st_off = lds_base + (unsigned)((kt % NST) * STAGE);
+    u32x4_t fa0[2], fb0[2], fa1[2], fb1[2];
+#define T2P_RD(S, FA, FB)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                  \
+    const unsigned aa = st_off + a_fo[i][S];                                                       \
+    const unsigned ba = st_off + b_fo[i][S];                                                       \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(FA[i]) : "v"(aa));                                   \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(FB[i]) : "v"(ba));                                   \
+  }
+#define T2P_WAIT(N, FA, FB) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FB[0]), "+v"(FB[1]))
+#define T2P_MMA(FA, FB)                                                                            \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)      \
+      Mma<TC>::run(__builtin_bit_cast(uint4, FA[i]), __builtin_bit_cast(uint4, FB[j]), acc[i][j]);
+    T2P_RD(0, fa0, fb0)
+    T2P_RD(1, fa1, fb1)
+    T2P_WAIT(4, fa0, fb0);
+    T2P_MMA(fa0, fb0)
+    T2P_RD(2, fa0, fb0)
+    T2P_WAIT(4, fa1, fb1);
+    T2P_MMA(fa1, fb1)
+    T2P_RD(3, fa1, fb1)
+    T2P_WAIT(4, fa0, fb0);
+    T2P_MMA(fa0, fb0)
+    T2P_WAIT(0, fa1, fb1);
+    T2P_MMA(fa1, fb1)
+#undef T2P_RD
+#undef T2P_WAIT
+#undef T2P_MMA
+  }
+
+  // ---- epilogue (same contract as v1) ---------------------------------------------------------
+  const long coff = (long)z0 * p.sC_z0 + (long)z1 * p.sC_z1;
+  const float* R = p.R ? p.R + (long)z0 * p.sR_z0 + (long)z1 * p.sR_z1 : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int row = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+      if (row >= p.M) continue;
+      const int bidx = row / p.rows_per_batch;
+      long rrow = row;
+      if (p.r_up) {
+        int rem = row - bidx * HW;
+        int y = rem / p.W, x = rem - y * p.W;
+        rrow = ((long)bidx * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
+      }
+      const float bm = p.bias_m ? p.bias_m[row] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + lr;
+        if (col >= p.N) continue;
+        float val = acc[i][j][v] + bm;
+        if (p.bias_n) val += p.bias_n[col];
+        if (p.bias_bn) val += p.bias_bn[(long)bidx * p.ld_bn + col];
+        if (R) val += R[rrow * p.ldr + col];
+        val *= p.alpha;
+        if (p.c_nchw) {
+          const int pix = row - bidx * p.rows_per_batch;
+          ((float*)p.C)[((long)bidx * p.N + col) * p.rows_per_batch + pix] = val * p.row_scale[bidx];
+        } else if (p.c_f32) {
+          ((float*)p.C)[coff + (long)row * p.ldc + col] = val;
+        } else {
+          ((TC*)p.C)[coff + (long)row * p.ldc + col] = from_f32<TC>(val);
+        }
+      }
+    }
+  }
+}
+
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream -----------
 struct ProfRec { hipEvent_t a, b; double flops; int kind; };
 static bool g_prof_on = false;
@@ -322,6 +573,50 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
   return T2P_OK;
 }
 
+static bool g_use_dma = true;
+void set_gemm_dma(bool on) { g_use_dma = on; }
+
+static bool dma_eligible(const GemmParams& p) {
+  if (!g_use_dma || p.dtype == DT_F32 || p.a_f32) return false;
+  const int Ctot = p.C0 + p.C1;
+  if (p.C0 % 64 != 0 || Ctot % 8 != 0) return false;
+  if (p.M < 256 || p.N < 64) return false;              // small problems: v1's 64x64 tiles fill the chip better
+  const long a_rows = (p.taps == 9 || p.a_up) ? (long)(p.M / (p.H * p.W)) * (p.a_up ? (p.H / 2) * (p.W / 2) : p.H * p.W) : p.M;
+  const long lim = (1L << 31) - 64;
+  if (a_rows * p.lda0 * 2 >= lim || (p.A1 && a_rows * p.lda1 * 2 >= lim)) return false;
+  if ((long)p.N * p.ldb * 2 >= lim) return false;
+  return true;
+}
+
+template <typename TC>
+static int launch_dma(const GemmParams& p, hipStream_t stream) {
+  constexpr int BM = 256, BN = 128;
+  constexpr int smem = 3 * (BM + BN) * 128;
+  static bool attr_set = false;
+  auto kern = gemm_dma_kernel<TC, BM, BN>;
+  if (!attr_set) {
+    T2P_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  dim3 grid(tiles_m * tiles_n, p.nz0 * p.nz1);
+  ProfRec rec;
+  if (g_prof_on) {
+    T2P_HIP_CHECK(hipEventCreate(&rec.a));
+    T2P_HIP_CHECK(hipEventCreate(&rec.b));
+    rec.flops = 2.0 * p.M * p.N * (double)p.taps * (p.C0 + p.C1) * p.nz0 * p.nz1;
+    rec.kind = p.taps == 9 ? 0 : 1;
+    T2P_HIP_CHECK(hipEventRecord(rec.a, stream));
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p, tiles_m, tiles_n);
+  if (g_prof_on) {
+    T2P_HIP_CHECK(hipEventRecord(rec.b, stream));
+    g_prof.push_back(rec);
+  }
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
 template <typename TC, bool AF32>
 static int launch_tile(const GemmParams& p, hipStream_t stream) {
   // small problems: 64x64 tiles give more workgroups and waste less on ragged edges
@@ -358,6 +653,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
   T2P_REQUIRE(((uintptr_t)p.A0 % 16) == 0 && ((uintptr_t)p.Bw % 16) == 0 && ((uintptr_t)p.A1 % 16) == 0,
               "operands must be 16-byte aligned");
   T2P_REQUIRE((long)(p.M + 127) / 128 < 65536, "M too large for grid.y");
+  if (dma_eligible(p)) return p.dtype == DT_BF16 ? launch_dma<bf16_t>(p, stream) : launch_dma<f16_t>(p, stream);
   switch (p.dtype) {
     case DT_F32: return launch_tile<float, true>(p, stream);
     case DT_BF16: return p.a_f32 ? launch_tile<bf16_t, true>(p, stream) : launch_tile<bf16_t, false>(p, stream);
