@@ -154,6 +154,9 @@ int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int
 /* ---- measurement hooks (bench.py): time every MFMA GEMM launch with HIP events on its stream ----
  * out6 = {conv3x3: ms, flops, launches, other GEMMs: ms, flops, launches} since t2p_profile_begin */
 int t2p_profile_begin(void);
+/* development switches: key 0 = enable (1) / disable (0) the LDS-DMA GEMM kernel; key 1 = timing-only
+ * ablation mask of that kernel (non-zero values produce wrong results; never set in product code) */
+int t2p_debug_set(int key, int value);
 int t2p_profile_end(double* out6);
 
 #ifdef __cplusplus

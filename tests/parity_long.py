@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--res", type=int, default=64)
     ap.add_argument("--dtypes", default="f32,f16,bf16")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "parity_long.json"))
+    ap.add_argument("--mode", default="all", choices=["all", "hip", "oracle", "compare"],
+                    help="hip: run the HIP engine and save outputs (GPU box); oracle: run the CPU oracle and save "
+                         "(any box: the noise comes from a seeded torch CPU generator); compare: read both")
     a = ap.parse_args()
     from oracle import t2p_oracle as O
     from text2protein_amd import sampling, sde_lib, synth
@@ -40,8 +43,15 @@ def main():
     res = {"config": f"test_config.yml L={L} N={N} B={B} T={a.tokens} steps={a.steps}", "dtypes": {}}
     sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=N)
     fn = sampling.get_sampling_fn(cfg, sde, (B, C_, L, L), 1e-5)
+    hip_file = os.path.join(ROOT, "gpurun_out", f"parity_long_hip_{a.res}_{a.steps}.pt")
+    ora_file = os.path.join(ROOT, "gpurun_out", f"parity_long_oracle_{a.res}_{a.steps}.pt")
+    os.makedirs(os.path.dirname(hip_file), exist_ok=True)
     got = {}
-    for dt in a.dtypes.split(","):
+    if a.mode in ("oracle", "compare"):
+        a.dtypes = ""
+    if a.mode == "compare":
+        got = torch.load(hip_file)
+    for dt in [d for d in a.dtypes.split(",") if d]:
         model = HipScoreModel(cfg, dtype=dt)
         model.load_state_dict(sd)
         it = iter(draws)
@@ -51,12 +61,29 @@ def main():
         got[dt] = out.cpu()
         print(f"[{dt}] HIP run {time.time() - t0:.1f}s finite={bool(torch.isfinite(out).all())}", flush=True)
         del model
-    t0 = time.time()
-    it = iter(draws)
-    trace = []
-    want, _ = O.pc_sampler_ve(sd, cfg, (B, C_, L, L), ctx, noise_fn=lambda s: next(it), n_steps_limit=a.steps, trace=trace)
-    res["oracle_seconds"] = time.time() - t0
-    print(f"oracle {res['oracle_seconds']:.1f}s on {torch.get_num_threads()} threads", flush=True)
+    if a.mode == "hip":
+        torch.save(got, hip_file)
+        print("saved", hip_file)
+        return
+    if a.mode == "compare":
+        want = torch.load(ora_file)
+    else:
+        t0 = time.time()
+        it = iter(draws)
+
+        class _Trace(list):
+            def append(self, v):
+                super().append(v)
+                if len(self) % 10 == 0:
+                    print(f"oracle step {len(self)} ({time.time() - t0:.0f}s)", flush=True)
+
+        want, _ = O.pc_sampler_ve(sd, cfg, (B, C_, L, L), ctx, noise_fn=lambda s: next(it), n_steps_limit=a.steps, trace=_Trace())
+        res["oracle_seconds"] = time.time() - t0
+        print(f"oracle {res['oracle_seconds']:.1f}s on {torch.get_num_threads()} threads", flush=True)
+        if a.mode == "oracle":
+            torch.save(want, ora_file)
+            print("saved", ora_file)
+            return
     for dt, o in got.items():
         e = float((o.double() - want.double()).norm() / want.double().norm())
         res["dtypes"][dt] = e

@@ -72,6 +72,7 @@ SIGNATURES = {
     "t2p_op_predictor": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _i, _vp]),
     "t2p_op_philox_normal": (_i, [_vp, _i64, _u64, _u64, _vp]),
     "t2p_profile_begin": (_i, []),
+    "t2p_debug_set": (_i, [_i, _i]),
     "t2p_profile_end": (_i, [C.POINTER(C.c_double)]),
     "t2p_op_convert": (_i, [_vp, _vp, _i, _i64, _vp]),
 }

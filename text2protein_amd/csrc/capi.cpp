@@ -306,6 +306,13 @@ int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int
   API_END
 }
 
+int t2p_debug_set(int key, int value) {
+  if (key == 0) set_gemm_dma(value != 0);
+  else if (key == 1) set_gemm_debug(value);
+  else return T2P_ERR_INVALID;
+  return T2P_OK;
+}
+
 int t2p_profile_begin(void) {
   profile_begin();
   return T2P_OK;

@@ -14,6 +14,7 @@
 //   * bf16 / fp16  : v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulate
 // LDS rows hold BK = 128 bytes of K (32 fp32 / 64 16-bit elements); a lane's fragment for
 // k-group s is the 16 bytes at [row][32 s + 16 (lane >> 5)], for both element widths.
+#include <algorithm>
 #include <vector>
 
 #include "t2p_common.h"
@@ -287,21 +288,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 //     ds_read_b128 fragment reads apply the same XOR (conflict-free for all 16-lane groups)
 //   * tile ids are remapped so that consecutive tiles (same A rows, neighbouring pixels) run on
 //     the same XCD and share its L2
-// Requirements (else v1 runs): 16-bit compute dtype, A in the compute dtype, C0 % 64 == 0,
-// (C0 + C1) % 8 == 0, every operand smaller than 2 GiB.
+// Requirements (else v1 runs): 16-bit compute dtype, A in the compute dtype, C0 % 64 == 0 and
+// C1 % 64 == 0, M >= 256, N >= 64, every operand smaller than 2 GiB.
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define T2P_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 static constexpr unsigned DMA_OOB = 0x80000000u;   // >= any num_records we accept -> zeros
 
-template <typename TC, int BM, int BN>
-__global__ __launch_bounds__(512) void gemm_dma_kernel(const GemmParams p, const int tiles_m, const int tiles_n) {
+// MODE 0: plain GEMM rows; 1: 3x3 convolution; 2: 3x3 convolution reading a half-resolution source
+template <typename TC, int BM, int BN, int MODE>
+__global__ __launch_bounds__(512) void gemm_dma_kernel(const GemmParams p, const int tiles_m, const int tiles_n, const int dbg) {
   constexpr int BK = 64;
   constexpr int NST = 3;
   constexpr int WM = BM / 64, WN = BN / 64;           // wave grid (4 x 2)
   static_assert(WM * WN == 8, "8 wavefronts");
   constexpr int A_INSTR = BM / 64, B_INSTR = BN / 64;  // DMA instructions per wave per K-tile (8 rows each)
   constexpr int STAGE = (BM + BN) * 128;
+  constexpr int TAPS = MODE == 0 ? 1 : 9;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -323,10 +326,9 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const GemmParams p, const
 
   const int Ctot = p.C0 + p.C1;
   const int nch = (Ctot + BK - 1) / BK;
-  const int nk = nch * p.taps;
-  const bool spatial = (p.taps == 9) || p.a_up;
+  const int nk = nch * TAPS;
   const int HW = p.H * p.W;
-  const int Hs = p.a_up ? (p.H >> 1) : p.H, Ws = p.a_up ? (p.W >> 1) : p.W;
+  const int Hs = MODE == 2 ? (p.H >> 1) : p.H, Ws = MODE == 2 ? (p.W >> 1) : p.W;
 
   // buffer descriptors: whole operand in range, everything else reads as zero.  Built from
   // readfirstlane'd scalars so that hipcc keeps them in SGPRs (no waterfall loop around the DMA).
@@ -337,84 +339,92 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const GemmParams p, const
     const int nb = __builtin_amdgcn_readfirstlane(bytes);
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, nb, 0x00020000);
   };
-  const long a_rows = spatial ? (long)(p.M / HW) * Hs * Ws : (long)p.M;
+  const long a_rows = MODE == 0 ? (long)p.M : (long)(p.M / HW) * Hs * Ws;
   const TC* A0p = (const TC*)p.A0 + (long)z0 * p.sA_z0 + (long)z1 * p.sA_z1;
   const TC* Bp = (const TC*)p.Bw + (long)z0 * p.sB_z0 + (long)z1 * p.sB_z1;
   const int a0_bytes = (int)(((a_rows - 1) * p.lda0 + p.C0) * 2);
   const int a1_bytes = p.A1 ? (int)(((a_rows - 1) * p.lda1 + p.C1) * 2) : 0;
-  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bp, (int)((((long)p.N - 1) * p.ldb + (long)p.taps * Ctot) * 2));
+  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bp, (int)((((long)p.N - 1) * p.ldb + (long)TAPS * Ctot) * 2));
+  const unsigned lda0_2 = (unsigned)(p.lda0 * 2), lda1_2 = (unsigned)(p.lda1 * 2);
 
-  // per-lane DMA geometry: instruction j of this wave covers tile rows (wave * INSTR + j) * 8 + (lane >> 3)
+  // per-lane DMA geometry: instruction j of this wave covers tile rows (wave * INSTR + j) * 8 + (lane >> 3).
+  // K order is chunk-major (all 9 taps of one 64-channel slice back to back: the 3x3 window
+  // re-reads stay in the XCD's L2).  For MODE 1 the source row of tap (dy, dx) is m + dy*W + dx
+  // (NHWC rows are pixel-major), so per K-tile the lane adds one wave-uniform byte delta to a
+  // precomputed offset; bit t of a_vm says whether tap t lands inside the map.
   const int prow = lane >> 3, ppos = lane & 7;
-  int a_b[A_INSTR], a_y[A_INSTR], a_x[A_INSTR];
-  unsigned a_chunk[A_INSTR];     // byte offset of this lane's (swizzled) source chunk inside the 128-byte K-slice
-  bool a_ok[A_INSTR];
+  unsigned a_off0[A_INSTR], a_off1[A_INSTR], a_vm[A_INSTR];
+  int a_y[A_INSTR], a_x[A_INSTR], a_bb[A_INSTR];       // MODE 2 only
 #pragma unroll
   for (int j = 0; j < A_INSTR; ++j) {
     const int r = (wave * A_INSTR + j) * 8 + prow;
     const int m = m0 + r;
-    a_ok[j] = m < p.M;
-    a_chunk[j] = (unsigned)((ppos ^ ((r >> 1) & 7)) * 16);
-    if (spatial) {
-      const int b = m / HW, rem = m - b * HW;
-      a_b[j] = b; a_y[j] = rem / p.W; a_x[j] = rem - a_y[j] * p.W;
-    } else {
-      a_b[j] = m; a_y[j] = 0; a_x[j] = 0;
+    const unsigned chunk = (unsigned)((ppos ^ ((r >> 1) & 7)) * 16);
+    unsigned vm = 0;
+    int y = 0, x = 0, b = 0;
+    if (MODE != 0) {
+      b = m / HW;
+      const int rem = m - b * HW;
+      y = rem / p.W;
+      x = rem - y * p.W;
     }
+    if (m < p.M) {
+      if (MODE == 0) {
+        vm = 1;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int sy = y + t / 3 - 1, sx = x + t % 3 - 1;
+          if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) vm |= 1u << t;
+        }
+      }
+    }
+    a_vm[j] = vm;
+    a_y[j] = y; a_x[j] = x; a_bb[j] = b * Hs * Ws;
+    a_off0[j] = (unsigned)m * lda0_2 + chunk;        // MODE 2 recomputes the row per tap
+    a_off1[j] = (unsigned)m * lda1_2 + chunk;
+    if (MODE == 2) { a_off0[j] = chunk; a_off1[j] = chunk; }
   }
-  unsigned b_off[B_INSTR], b_chunk[B_INSTR];
-  bool b_ok[B_INSTR];
+  unsigned b_off[B_INSTR];
 #pragma unroll
   for (int j = 0; j < B_INSTR; ++j) {
     const int r = (wave * B_INSTR + j) * 8 + prow;
     const int n = n0 + r;
-    b_ok[j] = n < p.N;
-    b_off[j] = (unsigned)((long)n * p.ldb * 2);
-    b_chunk[j] = (unsigned)((ppos ^ ((r >> 1) & 7)) * 16);
+    b_off[j] = n < p.N ? (unsigned)((long)n * p.ldb * 2) + (unsigned)((ppos ^ ((r >> 1) & 7)) * 16) : DMA_OOB;
   }
 
-  // source pixel row of each DMA row for the current tap (-1: outside the map / beyond M);
-  // recomputed only when the tap changes (every nch K-tiles)
-  int a_src[A_INSTR];
-  auto set_tap = [&](int tap) {
-    int dy = 0, dx = 0;
-    if (p.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
-#pragma unroll
-    for (int j = 0; j < A_INSTR; ++j) {
-      int row = a_b[j];
-      bool ok = a_ok[j];
-      if (spatial) {
-        int sy = a_y[j] + dy, sx = a_x[j] + dx;
-        ok = ok && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
-        if (p.a_up) { sy >>= 1; sx >>= 1; }
-        row = (a_b[j] * Hs + sy) * Ws + sx;
-      }
-      a_src[j] = ok ? row : -1;
-    }
-  };
-
-  auto issue = [&](int kt) {
+  auto issue = [&](int kt, int part) {   // part 0: A rows, 1: B rows, 2: both
     unsigned char* st = smem + (kt % NST) * STAGE;
-    const int tap = kt / nch;
-    const int c0 = (kt - tap * nch) * BK;              // channel base of this K-tile
-    if (c0 == 0) set_tap(tap);
+    const int chunk = kt / TAPS;
+    const int tap = kt - chunk * TAPS;
+    const int c0 = chunk * BK;                         // channel base of this K-tile
+    int dy = 0, dx = 0;
+    if (MODE != 0) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
     const bool second = c0 >= p.C0;                    // wave-uniform: C0 % 64 == 0
     const int csrc = second ? c0 - p.C0 : c0;
-    const int cend = second ? p.C1 : p.C0;             // channels available in this source
-    const unsigned ld2 = (unsigned)((second ? p.lda1 : p.lda0) * 2);
+    const unsigned ld2 = second ? lda1_2 : lda0_2;
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(second ? (const void*)p.A1 : (const void*)A0p, second ? a1_bytes : a0_bytes);
+    const unsigned udelta = (unsigned)((dy * p.W + dx) * (int)ld2 + csrc * 2);   // wave-uniform
+    const unsigned tbit = 1u << tap;
+    if (part != 1)
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
-      const bool ok = a_src[j] >= 0 && (csrc + (int)(a_chunk[j] >> 1) < cend);
-      const unsigned voff = ok ? (unsigned)a_src[j] * ld2 + (unsigned)(csrc * 2) + a_chunk[j] : DMA_OOB;
+      const bool ok = (a_vm[j] & tbit) != 0;
+      unsigned voff;
+      if (MODE == 2) {
+        const int row = a_bb[j] + ((a_y[j] + dy) >> 1) * Ws + ((a_x[j] + dx) >> 1);
+        voff = (unsigned)row * ld2 + (unsigned)(csrc * 2) + a_off0[j];
+      } else {
+        voff = (second ? a_off1[j] : a_off0[j]) + udelta;
+      }
       unsigned char* dst = st + (wave * A_INSTR + j) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, T2P_LDS_PTR(dst), 16, voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, T2P_LDS_PTR(dst), 16, ok ? voff : DMA_OOB, 0, 0, 0);
     }
     const unsigned kb = (unsigned)(((long)tap * Ctot + c0) * 2);
+    if (part != 0)
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j) {
-      const bool ok = b_ok[j] && (c0 + (int)(b_chunk[j] >> 1) < Ctot);
-      const unsigned voff = ok ? b_off[j] + kb + b_chunk[j] : DMA_OOB;
+      const unsigned voff = b_off[j] + kb;   // rows beyond N carry DMA_OOB: adding kb (< 2 GiB) keeps them out of range
       unsigned char* dst = st + BM * 128 + (wave * B_INSTR + j) * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, T2P_LDS_PTR(dst), 16, voff, 0, 0, 0);
     }
@@ -429,25 +439,27 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const GemmParams p, const
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
   // fragment read offsets: row (wm*64 + i*32 + lr), chunk (2 s + lh) ^ ((row >> 1) & 7)
-  unsigned a_fo[2][4], b_fo[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ra = wm * 64 + i * 32 + lr, rb = wn * 64 + i * 32 + lr;
+  // (the second 32-row tile of a wave is 32 rows = 4096 bytes further and has the same swizzle
+  // term, so it is reached through the ds_read immediate offset)
+  unsigned a_fo[4], b_fo[4];
+  {
+    const int ra = wm * 64 + lr, rb = wn * 64 + lr;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      a_fo[i][s] = (unsigned)(ra * 128 + (((2 * s + lh) ^ ((ra >> 1) & 7)) << 4));
-      b_fo[i][s] = (unsigned)(BM * 128 + rb * 128 + (((2 * s + lh) ^ ((rb >> 1) & 7)) << 4));
+      a_fo[s] = (unsigned)(ra * 128 + (((2 * s + lh) ^ ((ra >> 1) & 7)) << 4));
+      b_fo[s] = (unsigned)(BM * 128 + rb * 128 + (((2 * s + lh) ^ ((rb >> 1) & 7)) << 4));
     }
   }
 
   const unsigned lds_base = (unsigned)(unsigned long long)T2P_LDS_PTR(smem);
-  issue(0);
-  if (nk > 1) issue(1);
+  issue(0, 2);
+  if (nk > 1) issue(1, 2);
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + B_INSTR) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) issue(kt + 2);
+    const bool more = kt + 2 < nk && !(dbg & 2);
+    if (dbg & 4) { if (more) issue(kt + 2, 2); continue; }
     // Fragment reads go through inline asm: hipcc would otherwise put `s_waitcnt vmcnt(0)` in
     // front of every ds_read that may alias an in-flight LDS-DMA write and drain the ring.  The
     // reads of k-step s+1 are in flight while the MFMAs of step s run (lgkmcnt counts LDS ops in
@@ -455,23 +467,30 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const GemmParams p, const
     const unsigned st_off = lds_base + (unsigned)((kt % NST) * STAGE);
     u32x4_t fa0[2], fb0[2], fa1[2], fb1[2];
 #define T2P_RD(S, FA, FB)                                                                          \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                  \
-    const unsigned aa = st_off + a_fo[i][S];                                                       \
-    const unsigned ba = st_off + b_fo[i][S];                                                       \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(FA[i]) : "v"(aa));                                   \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(FB[i]) : "v"(ba));                                   \
+  {                                                                                                \
+    const unsigned aa = st_off + a_fo[S];                                                          \
+    const unsigned ba = st_off + b_fo[S];                                                          \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(FA[0]) : "v"(aa));                                   \
+    asm volatile("ds_read_b128 %0, %1" : "=v"(FB[0]) : "v"(ba));                                   \
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(FA[1]) : "v"(aa));                       \
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(FB[1]) : "v"(ba));                       \
   }
 #define T2P_WAIT(N, FA, FB) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FB[0]), "+v"(FB[1]))
 #define T2P_MMA(FA, FB)                                                                            \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)      \
       Mma<TC>::run(__builtin_bit_cast(uint4, FA[i]), __builtin_bit_cast(uint4, FB[j]), acc[i][j]);
+    // The fragment reads start right after the barrier; the DMA of K-tile kt+2 (address VALU +
+    // 6 buffer_load...lds) is issued between MFMA groups so that it overlaps the matrix pipe
+    // instead of holding every wave of the workgroup in a VALU-only phase.
     T2P_RD(0, fa0, fb0)
     T2P_RD(1, fa1, fb1)
     T2P_WAIT(4, fa0, fb0);
     T2P_MMA(fa0, fb0)
+    if (more) issue(kt + 2, 0);
     T2P_RD(2, fa0, fb0)
     T2P_WAIT(4, fa1, fb1);
     T2P_MMA(fa1, fb1)
+    if (more) issue(kt + 2, 1);
     T2P_RD(3, fa1, fb1)
     T2P_WAIT(4, fa0, fb0);
     T2P_MMA(fa0, fb0)
@@ -482,40 +501,84 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const GemmParams p, const
 #undef T2P_MMA
   }
 
-  // ---- epilogue (same contract as v1) ---------------------------------------------------------
+  // ---- epilogue ----------------------------------------------------------------------------------
+  // The accumulators (row-per-register, column-per-lane) are staged through this wave's private
+  // 16 KiB slice of the now idle LDS ring and read back row-contiguous, so that bias / residual
+  // loads and the output stores are 16-byte vectors covering whole 256-byte row segments (the
+  // per-lane dword stores of v1 are store-issue bound: 64 instructions per wave instead of 16).
+  if ((dbg & 1) && acc[0][0][0] != 123.456f) return;
+  __builtin_amdgcn_s_barrier();                       // every wave is done reading the last stage
+  float* stg = (float*)(smem + wave * 16384);         // [64 rows][64 cols] fp32
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) stg[(i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 64 + j * 32 + lr] = acc[i][j][v];
+  // same-wave LDS write -> read: the compiler orders them (lgkmcnt); no barrier needed
   const long coff = (long)z0 * p.sC_z0 + (long)z1 * p.sC_z1;
   const float* R = p.R ? p.R + (long)z0 * p.sR_z0 + (long)z1 * p.sR_z1 : nullptr;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int row = m0 + wm * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
-      if (row >= p.M) continue;
-      const int bidx = row / p.rows_per_batch;
-      long rrow = row;
-      if (p.r_up) {
-        int rem = row - bidx * HW;
-        int y = rem / p.W, x = rem - y * p.W;
-        rrow = ((long)bidx * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
+  const bool need_b = p.bias_bn || p.r_up;
+  const int rpb = p.rows_per_batch;
+  const int b_first = need_b ? m0 / rpb : 0;          // a 256-row tile spans at most two samples when rpb >= BM
+  const int b_edge = (b_first + 1) * rpb;
+  const int cq = (lane & 15) * 4;                     // this lane's 4 columns inside the wave tile
+  const int col = n0 + wn * 64 + cq;
+  const bool full4 = col + 3 < p.N;
+  float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias_n) {
+    if (full4) bn = *(const float4*)(p.bias_n + col);
+    else {
+      if (col < p.N) bn.x = p.bias_n[col];
+      if (col + 1 < p.N) bn.y = p.bias_n[col + 1];
+      if (col + 2 < p.N) bn.z = p.bias_n[col + 2];
+    }
+  }
+  const bool vec_ok = full4 && (p.ldc % 4 == 0) && (!R || p.ldr % 4 == 0) && (!p.bias_bn || p.ld_bn % 4 == 0);
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int rl = it * 4 + (lane >> 4);
+    const int row = m0 + wm * 64 + rl;
+    if (row >= p.M || col >= p.N) continue;
+    float4 a = *(const float4*)(stg + rl * 64 + cq);
+    int bidx = 0;
+    if (need_b) bidx = rpb >= BM ? b_first + (row >= b_edge ? 1 : 0) : row / rpb;
+    long rrow = row;
+    if (p.r_up) {
+      const int rem = row - bidx * HW;
+      const int y = rem / p.W, x = rem - y * p.W;
+      rrow = ((long)bidx * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
+    }
+    const float bm = p.bias_m ? p.bias_m[row] : 0.f;
+    a.x += bm + bn.x; a.y += bm + bn.y; a.z += bm + bn.z; a.w += bm + bn.w;
+    if (vec_ok) {
+      if (p.bias_bn) {
+        const float4 t = *(const float4*)(p.bias_bn + (long)bidx * p.ld_bn + col);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
       }
-      const float bm = p.bias_m ? p.bias_m[row] : 0.f;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + lr;
-        if (col >= p.N) continue;
-        float val = acc[i][j][v] + bm;
-        if (p.bias_n) val += p.bias_n[col];
-        if (p.bias_bn) val += p.bias_bn[(long)bidx * p.ld_bn + col];
-        if (R) val += R[rrow * p.ldr + col];
+      if (R) {
+        const float4 t = *(const float4*)(R + rrow * p.ldr + col);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
+      a.x *= p.alpha; a.y *= p.alpha; a.z *= p.alpha; a.w *= p.alpha;
+      if (p.c_f32) {
+        *(float4*)((float*)p.C + coff + (long)row * p.ldc + col) = a;
+      } else {
+        TC* dst = (TC*)p.C + coff + (long)row * p.ldc + col;
+        union { TC e[4]; uint2 u; } o;
+        o.e[0] = from_f32<TC>(a.x); o.e[1] = from_f32<TC>(a.y); o.e[2] = from_f32<TC>(a.z); o.e[3] = from_f32<TC>(a.w);
+        *(uint2*)dst = o.u;
+      }
+    } else {
+      float vals[4] = {a.x, a.y, a.z, a.w};
+      for (int k = 0; k < 4; ++k) {
+        if (col + k >= p.N) break;
+        float val = vals[k];
+        if (p.bias_bn) val += p.bias_bn[(long)bidx * p.ld_bn + col + k];
+        if (R) val += R[rrow * p.ldr + col + k];
         val *= p.alpha;
-        if (p.c_nchw) {
-          const int pix = row - bidx * p.rows_per_batch;
-          ((float*)p.C)[((long)bidx * p.N + col) * p.rows_per_batch + pix] = val * p.row_scale[bidx];
-        } else if (p.c_f32) {
-          ((float*)p.C)[coff + (long)row * p.ldc + col] = val;
-        } else {
-          ((TC*)p.C)[coff + (long)row * p.ldc + col] = from_f32<TC>(val);
-        }
+        if (p.c_f32) ((float*)p.C)[coff + (long)row * p.ldc + col + k] = val;
+        else ((TC*)p.C)[coff + (long)row * p.ldc + col + k] = from_f32<TC>(val);
       }
     }
   }
@@ -574,13 +637,18 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
 }
 
 static bool g_use_dma = true;
+static int g_dbg = 0;   // timing-only ablations (results are wrong when non-zero): 1 no epilogue, 2 no DMA in loop, 4 no reads/MFMA
 void set_gemm_dma(bool on) { g_use_dma = on; }
+void set_gemm_debug(int v) { g_dbg = v; }
 
 static bool dma_eligible(const GemmParams& p) {
   if (!g_use_dma || p.dtype == DT_F32 || p.a_f32) return false;
   const int Ctot = p.C0 + p.C1;
-  if (p.C0 % 64 != 0 || Ctot % 8 != 0) return false;
+  if (p.C0 % 64 != 0 || p.C1 % 64 != 0) return false;   // whole 64-channel K-tiles only (else v1)
   if (p.M < 256 || p.N < 64) return false;              // small problems: v1's 64x64 tiles fill the chip better
+  if (p.a_up && p.taps != 9) return false;
+  if (p.c_nchw) return false;
+  if (((long)p.M + 256) * std::max(p.lda0, p.lda1) * 2 >= (1L << 31)) return false;   // 32-bit offset arithmetic
   const long a_rows = (p.taps == 9 || p.a_up) ? (long)(p.M / (p.H * p.W)) * (p.a_up ? (p.H / 2) * (p.W / 2) : p.H * p.W) : p.M;
   const long lim = (1L << 31) - 64;
   if (a_rows * p.lda0 * 2 >= lim || (p.A1 && a_rows * p.lda1 * 2 >= lim)) return false;
@@ -588,12 +656,12 @@ static bool dma_eligible(const GemmParams& p) {
   return true;
 }
 
-template <typename TC>
-static int launch_dma(const GemmParams& p, hipStream_t stream) {
+template <typename TC, int MODE>
+static int launch_dma_mode(const GemmParams& p, hipStream_t stream) {
   constexpr int BM = 256, BN = 128;
   constexpr int smem = 3 * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = gemm_dma_kernel<TC, BM, BN>;
+  auto kern = gemm_dma_kernel<TC, BM, BN, MODE>;
   if (!attr_set) {
     T2P_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
@@ -608,13 +676,19 @@ static int launch_dma(const GemmParams& p, hipStream_t stream) {
     rec.kind = p.taps == 9 ? 0 : 1;
     T2P_HIP_CHECK(hipEventRecord(rec.a, stream));
   }
-  hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p, tiles_m, tiles_n);
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p, tiles_m, tiles_n, g_dbg);
   if (g_prof_on) {
     T2P_HIP_CHECK(hipEventRecord(rec.b, stream));
     g_prof.push_back(rec);
   }
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
+}
+
+template <typename TC>
+static int launch_dma(const GemmParams& p, hipStream_t stream) {
+  if (p.taps == 9) return p.a_up ? launch_dma_mode<TC, 2>(p, stream) : launch_dma_mode<TC, 1>(p, stream);
+  return launch_dma_mode<TC, 0>(p, stream);
 }
 
 template <typename TC, bool AF32>

@@ -120,6 +120,7 @@ struct GemmParams {
 
 int launch_gemm(const GemmParams& p, hipStream_t stream);
 void set_gemm_dma(bool on);
+void set_gemm_debug(int v);
 void profile_begin();
 int profile_end(double out[2][3]);
 
