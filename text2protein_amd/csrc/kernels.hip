@@ -64,8 +64,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormArgs a, int nchu
     const int c = c_lo + v * 4;
     const float* src; long ld; int cc;
     if (c < a.C0) { src = a.x0; ld = a.C0; cc = c; } else { src = a.x1; ld = a.C1; cc = c - a.C0; }
-    for (int p = p_lo + po; p < p_hi; p += ppi) {
-      float4 t = *(const float4*)(src + ((long)b * a.HW + p) * ld + cc);
+    const float* base = src + (long)b * a.HW * ld + cc;
+    int p = p_lo + po;
+    for (; p + 3 * ppi < p_hi; p += 4 * ppi) {       // four independent 16-byte loads in flight
+      const float4 t0 = *(const float4*)(base + (long)p * ld);
+      const float4 t1 = *(const float4*)(base + (long)(p + ppi) * ld);
+      const float4 t2 = *(const float4*)(base + (long)(p + 2 * ppi) * ld);
+      const float4 t3 = *(const float4*)(base + (long)(p + 3 * ppi) * ld);
+      s0 += (t0.x + t1.x) + (t2.x + t3.x); s1 += (t0.y + t1.y) + (t2.y + t3.y);
+      s2 += (t0.z + t1.z) + (t2.z + t3.z); s3 += (t0.w + t1.w) + (t2.w + t3.w);
+      q0 += (t0.x * t0.x + t1.x * t1.x) + (t2.x * t2.x + t3.x * t3.x);
+      q1 += (t0.y * t0.y + t1.y * t1.y) + (t2.y * t2.y + t3.y * t3.y);
+      q2 += (t0.z * t0.z + t1.z * t1.z) + (t2.z * t2.z + t3.z * t3.z);
+      q3 += (t0.w * t0.w + t1.w * t1.w) + (t2.w * t2.w + t3.w * t3.w);
+    }
+    for (; p < p_hi; p += ppi) {
+      const float4 t = *(const float4*)(base + (long)p * ld);
       s0 += t.x; s1 += t.y; s2 += t.z; s3 += t.w;
       q0 += t.x * t.x; q1 += t.y * t.y; q2 += t.z * t.z; q3 += t.w * t.w;
     }
@@ -127,43 +141,62 @@ int launch_gn_stats(const GroupNormArgs& a, hipStream_t s) {
 }
 
 // ================================== GroupNorm apply (+SiLU, +2x2 mean) ==========================
+__device__ inline float silu_fast(float x) { return x * __frcp_rn(1.f + __expf(-x)); }
+
+// grid (pixel chunks, B, ceil(C / 1024)).  A thread keeps one 4-channel vector: its scale/shift
+// (rstd*gamma, beta - mean*rstd*gamma) are computed once, then it walks output pixels with 32-bit
+// indexing; consecutive lanes cover consecutive channels (coalesced 16-byte loads, 8/16-byte stores).
+static constexpr int GNA_PIX_PER_BLOCK = 64;
+
 template <typename TO>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormApplyArgs a) {
   const int C = a.C0 + a.C1;
-  const int nvec = C >> 2;
   const int Ho = a.down ? a.H >> 1 : a.H, Wo = a.down ? a.W >> 1 : a.W;
-  const long total = (long)a.B * Ho * Wo * nvec;
+  const int HWo = Ho * Wo;
+  const int b = blockIdx.y, c_lo = blockIdx.z * 1024;
+  const int nvec = min(C - c_lo, 1024) >> 2;
+  const int ppi = 256 / nvec;
+  const int tid = threadIdx.x;
+  if (tid >= ppi * nvec) return;
+  const int v = tid % nvec, po = tid / nvec;
+  const int c = c_lo + v * 4;
   const int cpg = C / a.G;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int v = (int)(idx % nvec);
-    const long pix = idx / nvec;
-    const int b = (int)(pix / (Ho * Wo));
-    const int rem = (int)(pix - (long)b * Ho * Wo);
-    const int c = v * 4;
-    const float* src; long ld; int cc;
-    if (c < a.C0) { src = a.x0; ld = a.C0; cc = c; } else { src = a.x1; ld = a.C1; cc = c - a.C0; }
-    const float4 ga = *(const float4*)(a.gamma + c), be = *(const float4*)(a.beta + c);
-    float mean[4], rstd[4];
+  const float* src; int ld, cc;
+  if (c < a.C0) { src = a.x0; ld = a.C0; cc = c; } else { src = a.x1; ld = a.C1; cc = c - a.C0; }
+  src += (long)b * a.H * a.W * ld + cc;
+  const float4 ga = *(const float4*)(a.gamma + c), be = *(const float4*)(a.beta + c);
+  float sc[4], sh[4];
+  const float gv[4] = {ga.x, ga.y, ga.z, ga.w}, bv[4] = {be.x, be.y, be.z, be.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float* st = a.stats + ((long)b * a.G + (c + k) / cpg) * 2;
-      mean[k] = st[0]; rstd[k] = st[1];
+  for (int k = 0; k < 4; ++k) {
+    const float* st = a.stats + ((long)b * a.G + (c + k) / cpg) * 2;
+    sc[k] = st[1] * gv[k];
+    sh[k] = bv[k] - st[0] * sc[k];
+  }
+  TO* out = (TO*)a.out + (long)b * HWo * C + c;
+  const int p_lo = blockIdx.x * GNA_PIX_PER_BLOCK, p_hi = min(HWo, p_lo + GNA_PIX_PER_BLOCK);
+  if (!a.down) {
+#pragma unroll 2
+    for (int p = p_lo + po; p < p_hi; p += ppi) {
+      const float4 t = *(const float4*)(src + (long)p * ld);
+      float y0 = t.x * sc[0] + sh[0], y1 = t.y * sc[1] + sh[1], y2 = t.z * sc[2] + sh[2], y3 = t.w * sc[3] + sh[3];
+      if (a.silu) { y0 = silu_fast(y0); y1 = silu_fast(y1); y2 = silu_fast(y2); y3 = silu_fast(y3); }
+      store4<TO>(out + (long)p * C, y0, y1, y2, y3);
     }
-    float o[4] = {0, 0, 0, 0};
-    const int npx = a.down ? 4 : 1;
-    const int oy = rem / Wo, ox = rem - oy * Wo;
-    for (int q = 0; q < npx; ++q) {
-      const int iy = a.down ? 2 * oy + (q >> 1) : oy, ix = a.down ? 2 * ox + (q & 1) : ox;
-      const float4 t = *(const float4*)(src + (((long)b * a.H + iy) * a.W + ix) * ld + cc);
-      float y0 = (t.x - mean[0]) * rstd[0] * ga.x + be.x;
-      float y1 = (t.y - mean[1]) * rstd[1] * ga.y + be.y;
-      float y2 = (t.z - mean[2]) * rstd[2] * ga.z + be.z;
-      float y3 = (t.w - mean[3]) * rstd[3] * ga.w + be.w;
-      if (a.silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
-      o[0] += y0; o[1] += y1; o[2] += y2; o[3] += y3;
+  } else {
+    for (int p = p_lo + po; p < p_hi; p += ppi) {
+      const int oy = p / Wo, ox = p - oy * Wo;
+      float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ip = (2 * oy + (q >> 1)) * a.W + 2 * ox + (q & 1);
+        const float4 t = *(const float4*)(src + (long)ip * ld);
+        float y0 = t.x * sc[0] + sh[0], y1 = t.y * sc[1] + sh[1], y2 = t.z * sc[2] + sh[2], y3 = t.w * sc[3] + sh[3];
+        if (a.silu) { y0 = silu_fast(y0); y1 = silu_fast(y1); y2 = silu_fast(y2); y3 = silu_fast(y3); }
+        o0 += y0; o1 += y1; o2 += y2; o3 += y3;
+      }
+      store4<TO>(out + (long)p * C, o0 * 0.25f, o1 * 0.25f, o2 * 0.25f, o3 * 0.25f);
     }
-    if (a.down) { o[0] *= 0.25f; o[1] *= 0.25f; o[2] *= 0.25f; o[3] *= 0.25f; }
-    store4<TO>((TO*)a.out + pix * C + c, o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -177,8 +210,8 @@ int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s) {
   T2P_REQUIRE(a.x0 && a.stats && a.gamma && a.beta && a.out, "null pointer");
   T2P_REQUIRE(a.C0 % 4 == 0 && a.C1 % 4 == 0 && C % a.G == 0, "channel constraints");
   T2P_REQUIRE(!a.down || (a.H % 2 == 0 && a.W % 2 == 0), "down-sampling needs even H, W");
-  const long total = (long)a.B * (a.down ? a.H / 2 : a.H) * (a.down ? a.W / 2 : a.W) * (C / 4);
-  dim3 grid(ew_grid(total));
+  const int HWo = (a.down ? a.H / 2 : a.H) * (a.down ? a.W / 2 : a.W);
+  dim3 grid((HWo + GNA_PIX_PER_BLOCK - 1) / GNA_PIX_PER_BLOCK, a.B, (C + 1023) / 1024);
   switch (a.dtype) {
     case DT_F32: hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, a); break;
     case DT_BF16: hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, a); break;
@@ -246,7 +279,32 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float* S, long lds, 
   const int lane = threadIdx.x & 63;
   const float* sr = S + row * lds;
   TO* pr = P + row * ldp;
-  if (n <= 64 * SM_REGS) {
+  if (n <= 64 * SM_REGS && (n & 3) == 0 && (lds & 3) == 0 && (ldp & 3) == 0) {
+    // 16-byte loads, 8/16-byte stores: lane owns columns 4*lane + 256*i .. +3
+    float v[SM_REGS];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SM_REGS / 4; ++i) {
+      const int c = lane * 4 + 256 * i;
+      float4 t = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      if (c < n) { t = *(const float4*)(sr + c); t.x *= scale; t.y *= scale; t.z *= scale; t.w *= scale; }
+      v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+      m = fmaxf(m, fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w)));
+    }
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_REGS; ++i) {
+      v[i] = expf(v[i] - m);       // exp(-inf) = 0 for the columns beyond n
+      sum += v[i];
+    }
+    const float inv = 1.f / wave_sum(sum);
+#pragma unroll
+    for (int i = 0; i < SM_REGS / 4; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < ldp) store4<TO>(pr + c, v[4 * i] * inv, v[4 * i + 1] * inv, v[4 * i + 2] * inv, v[4 * i + 3] * inv);
+    }
+  } else if (n <= 64 * SM_REGS) {
     float v[SM_REGS];
     float m = -INFINITY;
 #pragma unroll
