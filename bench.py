@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="chains per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-geom", type=int, default=int(os.environ.get("T2P_GEMM_GEOM", "0")),
+                    help="development: 0 auto, 1 force 256x128x3, 2 force 128x128x2 LDS-DMA GEMM geometry")
     return ap.parse_args()
 
 
@@ -104,6 +106,11 @@ def main():
     N = cfg.model.num_scales
     C_, L = cfg.data.num_channels, cfg.data.max_res_num
 
+    if args.gemm_geom:
+        check(load().t2p_debug_set(2, args.gemm_geom))
+    for key, env in ((3, "T2P_SPLITK"), (4, "T2P_RAW_COPIES")):      # development A/B switches
+        if env in os.environ:
+            check(load().t2p_debug_set(key, int(os.environ[env])))
     t_setup = time.perf_counter()
     sd = synth.synth_state_dict(cfg, seed=0)                 # same weights on every rank (replicated model)
     model = HipScoreModel(cfg, dtype=args.dtype, device=str(dev))

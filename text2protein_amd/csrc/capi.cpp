@@ -309,6 +309,9 @@ int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int
 int t2p_debug_set(int key, int value) {
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) set_gemm_debug(value);
+  else if (key == 2) set_gemm_geom(value);
+  else if (key == 3) set_gemm_splitk(value != 0);
+  else if (key == 4) g_raw_copies = value != 0;
   else return T2P_ERR_INVALID;
   return T2P_OK;
 }

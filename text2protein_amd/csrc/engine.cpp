@@ -11,6 +11,7 @@
 
 namespace t2p {
 
+bool g_raw_copies = true;
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 const char* get_last_error() { return g_last_error.c_str(); }
@@ -446,6 +447,18 @@ int Engine::finalize() {
 }
 
 // ------------------------------------------------------------------------------------------------
+// every GEMM of the engine: lends the split-K workspace (fp32 partial tiles of low-resolution levels)
+int Engine::gemm(GemmParams& p, hipStream_t s) {
+  if (!splitk_ws_) {
+    splitk_ws_bytes_ = (size_t)64 << 20;
+    splitk_ws_ = pool_.persistent(splitk_ws_bytes_);
+    if (!splitk_ws_) return T2P_ERR_HIP;
+  }
+  p.ws = splitk_ws_;
+  p.ws_bytes = splitk_ws_bytes_;
+  return launch_gemm(p, s);
+}
+
 int Engine::linear(const void* a, bool a_is_f32, const DevLinear& w, long rows, void* c, bool c_f32,
                    const float* residual, float alpha, hipStream_t s, bool use_bias) {
   GemmParams p;
@@ -457,11 +470,11 @@ int Engine::linear(const void* a, bool a_is_f32, const DevLinear& w, long rows, 
   p.R = residual; p.ldr = w.N;
   p.alpha = alpha;
   p.C = c; p.c_f32 = c_f32; p.ldc = w.N;
-  return launch_gemm(p, s);
+  return gemm(p, s);
 }
 
 int Engine::group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps, int silu, int down, int B, void** out,
-                       hipStream_t s) {
+                       hipStream_t s, void** raw_out) {
   const int C = x.C + (x1 ? x1->C : 0);
   T2P_REQUIRE(C == n.C, "GroupNorm channel mismatch");
   GroupNormArgs a;
@@ -478,6 +491,11 @@ int Engine::group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps,
   const size_t opix = (size_t)B * (down ? x.H / 2 : x.H) * (down ? x.W / 2 : x.W);
   POOL_GET(o, void*, opix * C * dtype_size(dtype()));
   g.out = o;
+  if (raw_out) {
+    *raw_out = pool_.get(opix * C * dtype_size(dtype()));
+    if (!*raw_out) return T2P_ERR_HIP;
+    g.raw_out = *raw_out;
+  }
   T2P_TRY(launch_gn_apply(g, s));
   pool_.put(partial);
   pool_.put(stats);
@@ -494,7 +512,11 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
   const long rows_out = (long)B * Ho * Wo;
   const int dt = dtype();
   void* a0 = nullptr;
-  T2P_TRY(group_norm(x, skip, L.gn0, 1e-6f, 1, L.down, B, &a0, s));
+  // the 1x1 shortcut reads the raw block input: in 16-bit modes GroupNorm-apply (which reads it
+  // anyway) also emits it in the compute dtype, so the shortcut GEMM takes the LDS-DMA kernel
+  void* xraw = nullptr;
+  const bool want_raw = g_raw_copies && L.has_conv2 && !L.down && dt != DT_F32;
+  T2P_TRY(group_norm(x, skip, L.gn0, 1e-6f, 1, L.down, B, &a0, s, want_raw ? &xraw : nullptr));
   POOL_GET(h1, float*, (size_t)rows_out * Cout * 4);
   {
     GemmParams p;
@@ -503,7 +525,7 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     p.Bw = L.conv0.w; p.ldb = L.conv0.K; p.M = (int)rows_out; p.N = Cout;
     p.bias_n = L.conv0.b; p.bias_bn = tb_ + L.temb_off; p.ld_bn = tb_ld_; p.rows_per_batch = Ho * Wo;
     p.C = h1; p.c_f32 = 1; p.ldc = Cout;
-    T2P_TRY(launch_gemm(p, s));
+    T2P_TRY(gemm(p, s));
   }
   pool_.put(a0);
   Act h1a{h1, Cout, Ho, Wo};
@@ -516,18 +538,23 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
   int r_up = 0;
   if (L.has_conv2) {
     GemmParams p;
-    p.dtype = dt; p.a_f32 = 1;
-    float* pooled = nullptr;
+    p.dtype = dt; p.a_f32 = dt == DT_F32;
+    void* pooled = nullptr;
     long rrows;
     if (L.down) {
-      pooled = (float*)pool_.get((size_t)rows_out * Cin * 4);
+      pooled = pool_.get((size_t)rows_out * Cin * dtype_size(dt));
       if (!pooled) return T2P_ERR_HIP;
-      T2P_TRY(launch_pool2x2(x.p, pooled, B, x.H, x.W, Cin, s));
+      T2P_TRY(launch_pool2x2(x.p, pooled, dt, B, x.H, x.W, Cin, s));
       p.A0 = pooled; p.C0 = Cin; p.lda0 = Cin;
       rrows = rows_out;
     } else {
-      p.A0 = x.p; p.C0 = x.C; p.lda0 = x.C;
-      if (skip) { p.A1 = skip->p; p.C1 = skip->C; p.lda1 = skip->C; }
+      if (xraw) {
+        p.A0 = xraw; p.C0 = Cin; p.lda0 = Cin;
+      } else {
+        p.a_f32 = 1;
+        p.A0 = x.p; p.C0 = x.C; p.lda0 = x.C;
+        if (skip) { p.A1 = skip->p; p.C1 = skip->C; p.lda1 = skip->C; }
+      }
       rrows = (long)B * x.H * x.W;   // for `up` the 1x1 conv runs at the low resolution: it commutes
       r_up = L.up;                   // with nearest up-sampling exactly
     }
@@ -535,8 +562,9 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     if (!rbuf) return T2P_ERR_HIP;
     p.Bw = L.conv2.w; p.ldb = L.conv2.K; p.M = (int)rrows; p.N = Cout; p.bias_n = L.conv2.b;
     p.C = rbuf; p.c_f32 = 1; p.ldc = Cout;
-    T2P_TRY(launch_gemm(p, s));
+    T2P_TRY(gemm(p, s));
     pool_.put(pooled);
+    pool_.put(xraw);
     r = rbuf;
   } else {
     T2P_REQUIRE(!skip && Cin == Cout, "identity shortcut needs equal channels");
@@ -551,7 +579,7 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     p.R = r; p.ldr = Cout; p.r_up = r_up;
     p.alpha = cfg_.skip_rescale ? 0.70710678118654752440f : 1.f;
     p.C = o; p.c_f32 = 1; p.ldc = Cout;
-    T2P_TRY(launch_gemm(p, s));
+    T2P_TRY(gemm(p, s));
   }
   pool_.put(a1);
   pool_.put(rbuf);
@@ -574,7 +602,7 @@ int Engine::attention(const void* q, long ldq, const void* k, long ldk, const vo
   p.nz0 = B; p.nz1 = heads;
   p.sA_z0 = (long)nq * ldq; p.sA_z1 = d; p.sB_z0 = (long)nk * ldk; p.sB_z1 = d;
   p.C = S; p.c_f32 = 1; p.ldc = nkp; p.sC_z0 = (long)heads * nq * nkp; p.sC_z1 = (long)nq * nkp;
-  T2P_TRY(launch_gemm(p, s));
+  T2P_TRY(gemm(p, s));
   T2P_TRY(launch_softmax(S, nkp, P, nkp, dt, rows, nk, scale, s));
   GemmParams r;
   r.dtype = dt; r.a_f32 = dt == DT_F32;
@@ -672,10 +700,15 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     T2P_TRY(linear(g, false, L.ff2, rows, t, true, t, 1.f, s));
     pool_.put(g);
   }
-  pool_.put(ln);
   pool_.put(o);
   POOL_GET(y, float*, (size_t)rows * C * 4);
-  T2P_TRY(linear(t, true, L.proj_out, rows, y, true, x.p, 1.f, s));
+  if (dt != DT_F32 && g_raw_copies) {
+    T2P_TRY(launch_convert(t, ln, dt, rows * C, s));     // residual stream -> compute dtype (reuses the LN buffer)
+    T2P_TRY(linear(ln, false, L.proj_out, rows, y, true, x.p, 1.f, s));
+  } else {
+    T2P_TRY(linear(t, true, L.proj_out, rows, y, true, x.p, 1.f, s));
+  }
+  pool_.put(ln);
   pool_.put(t);
   *out = Act{y, C, x.H, x.W};
   return T2P_OK;
@@ -769,7 +802,7 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
     p.Bw = pre_conv_.w; p.ldb = pre_conv_.K; p.M = B * HW; p.N = nf_; p.bias_n = pre_conv_.b;
     p.rows_per_batch = HW;
     p.C = h0; p.c_f32 = 1; p.ldc = nf_;
-    T2P_TRY(launch_gemm(p, s));
+    T2P_TRY(gemm(p, s));
   }
   pool_.put(xin);
   pool_.put(emb); pool_.put(t1); pool_.put(t2);
@@ -804,7 +837,7 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
     p.Bw = head_conv_.w; p.ldb = head_conv_.K; p.M = B * HW; p.N = Cx; p.bias_n = head_conv_.b;
     p.rows_per_batch = HW;
     p.C = out; p.c_f32 = 1; p.c_nchw = 1; p.row_scale = scale;
-    T2P_TRY(launch_gemm(p, s));
+    T2P_TRY(gemm(p, s));
   }
   pool_.put(a);
   pool_.put(scale);

@@ -106,7 +106,8 @@ class Engine {
   int attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s);
   int st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s);
   int group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps, int silu, int down, int B, void** out,
-                 hipStream_t s);
+                 hipStream_t s, void** raw_out = nullptr);
+  int gemm(GemmParams& p, hipStream_t s);
   int attention(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, int B,
                 int heads, int nq, int nk, int d, float scale, hipStream_t s);
   int linear(const void* a, bool a_is_f32, const DevLinear& w, long rows, void* c, bool c_f32, const float* residual,
@@ -126,6 +127,8 @@ class Engine {
   int temb_total_ = 0;
   float* inv_sigma_ = nullptr;  // [N] fp32, 1 / sigmas[label] (descending sigmas)
   int ctx_B_ = 0, ctx_T_ = 0, ctx_Tpad_ = 0;
+  void* splitk_ws_ = nullptr;
+  size_t splitk_ws_bytes_ = 0;
   const float* tb_ = nullptr;   // per-eval temb biases [R][temb_total_]
   long tb_ld_ = 0;
   friend class Sampler;

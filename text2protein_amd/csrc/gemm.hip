@@ -296,13 +296,19 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 static constexpr unsigned DMA_OOB = 0x80000000u;   // >= any num_records we accept -> zeros
 
 // MODE 0: plain GEMM rows; 1: 3x3 convolution; 2: 3x3 convolution reading a half-resolution source
-template <typename TC, int BM, int BN, int MODE>
-__global__ __launch_bounds__(512) void gemm_dma_kernel(const GemmParams p, const int tiles_m, const int tiles_n, const int dbg) {
+//
+// Two geometries are instantiated:
+//   256 x 128, 8 wavefronts, 3-stage ring (144 KiB): one workgroup per CU, loads two K-tiles ahead
+//   128 x 128, 4 wavefronts, 2-stage ring ( 64 KiB): two workgroups per CU -- their barriers,
+//       prologues and epilogues overlap each other's MFMA phases
+template <typename TC, int BM, int BN, int MODE, int NST>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_dma_kernel(const GemmParams p, const int tiles_m, const int tiles_n, const int dbg) {
   constexpr int BK = 64;
-  constexpr int NST = 3;
-  constexpr int WM = BM / 64, WN = BN / 64;           // wave grid (4 x 2)
-  static_assert(WM * WN == 8, "8 wavefronts");
-  constexpr int A_INSTR = BM / 64, B_INSTR = BN / 64;  // DMA instructions per wave per K-tile (8 rows each)
+  constexpr int WM = BM / 64, WN = BN / 64;           // wave grid
+  constexpr int NW = WM * WN;
+  static_assert(NW == 8 || NW == 4, "4 or 8 wavefronts");
+  static_assert(NW * 16384 <= NST * (BM + BN) * 128, "epilogue staging must fit the ring");
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;  // DMA instructions per wave per K-tile (8 rows each)
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int TAPS = MODE == 0 ? 1 : 9;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -326,7 +332,11 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const GemmParams p, const
 
   const int Ctot = p.C0 + p.C1;
   const int nch = (Ctot + BK - 1) / BK;
-  const int nk = nch * TAPS;
+  const int nk_all = nch * TAPS;
+  // split-K: blockIdx.z owns K-tiles [kt_lo, kt_hi) and writes a raw fp32 partial tile
+  const int nsplit = gridDim.z, ks = blockIdx.z;
+  const int kt_lo = (int)((long)nk_all * ks / nsplit), kt_hi = (int)((long)nk_all * (ks + 1) / nsplit);
+  const int nk = kt_hi - kt_lo;
   const int HW = p.H * p.W;
   const int Hs = MODE == 2 ? (p.H >> 1) : p.H, Ws = MODE == 2 ? (p.W >> 1) : p.W;
 
@@ -393,8 +403,9 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const GemmParams p, const
     b_off[j] = n < p.N ? (unsigned)((long)n * p.ldb * 2) + (unsigned)((ppos ^ ((r >> 1) & 7)) * 16) : DMA_OOB;
   }
 
-  auto issue = [&](int kt, int part) {   // part 0: A rows, 1: B rows, 2: both
-    unsigned char* st = smem + (kt % NST) * STAGE;
+  auto issue = [&](int kl, int part) {   // part 0: A rows, 1: B rows, 2: both; kl counts from this block's first K-tile
+    unsigned char* st = smem + (kl % NST) * STAGE;
+    const int kt = kt_lo + kl;
     const int chunk = kt / TAPS;
     const int tap = kt - chunk * TAPS;
     const int c0 = chunk * BK;                         // channel base of this K-tile
@@ -452,14 +463,16 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const GemmParams p, const
   }
 
   const unsigned lds_base = (unsigned)(unsigned long long)T2P_LDS_PTR(smem);
+  constexpr int AHEAD = NST - 1;                       // K-tiles in flight beyond the one being multiplied
   issue(0, 2);
-  if (nk > 1) issue(1, 2);
+  if (AHEAD > 1 && nk > 1) issue(1, 2);
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + B_INSTR) : "memory");
+    // tile kt has landed when at most (AHEAD - 1) later tiles' loads are still outstanding
+    if (AHEAD > 1 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + B_INSTR) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const bool more = kt + 2 < nk && !(dbg & 2);
-    if (dbg & 4) { if (more) issue(kt + 2, 2); continue; }
+    if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
+    const bool more = kt + AHEAD < nk && !(dbg & 2);
+    if (dbg & 4) { if (more) issue(kt + AHEAD, 2); continue; }
     // Fragment reads go through inline asm: hipcc would otherwise put `s_waitcnt vmcnt(0)` in
     // front of every ds_read that may alias an in-flight LDS-DMA write and drain the ring.  The
     // reads of k-step s+1 are in flight while the MFMAs of step s run (lgkmcnt counts LDS ops in
@@ -486,11 +499,19 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const GemmParams p, const
     T2P_RD(1, fa1, fb1)
     T2P_WAIT(4, fa0, fb0);
     T2P_MMA(fa0, fb0)
-    if (more) issue(kt + 2, 0);
+    if (more) issue(kt + AHEAD, 0);
+    if (dbg & 16) {          // timing probe: half the fragment reads
+      T2P_WAIT(0, fa1, fb1);
+      T2P_MMA(fa1, fb1)
+      if (more) issue(kt + AHEAD, 1);
+      T2P_MMA(fa0, fb0)
+      T2P_MMA(fa1, fb1)
+      continue;
+    }
     T2P_RD(2, fa0, fb0)
     T2P_WAIT(4, fa1, fb1);
     T2P_MMA(fa1, fb1)
-    if (more) issue(kt + 2, 1);
+    if (more) issue(kt + AHEAD, 1);
     T2P_RD(3, fa1, fb1)
     T2P_WAIT(4, fa0, fb0);
     T2P_MMA(fa0, fb0)
@@ -516,14 +537,33 @@ __global__ __launch_bounds__(512) void gemm_dma_kernel(const GemmParams p, const
 #pragma unroll
       for (int v = 0; v < 16; ++v) stg[(i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 64 + j * 32 + lr] = acc[i][j][v];
   // same-wave LDS write -> read: the compiler orders them (lgkmcnt); no barrier needed
+  const int cq = (lane & 15) * 4;                     // this lane's 4 columns inside the wave tile
+  const int col = n0 + wn * 64 + cq;
+  if (nsplit > 1) {                                   // raw partial sums -> workspace [split][M][N]
+    float* ws = (float*)p.ws + (long)ks * p.M * p.N;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int rl = it * 4 + (lane >> 4);
+      const int row = m0 + wm * 64 + rl;
+      if (row >= p.M || col >= p.N) continue;
+      const float4 a = *(const float4*)(stg + rl * 64 + cq);
+      float* dst = ws + (long)row * p.N + col;
+      if (col + 3 < p.N && (p.N & 3) == 0) *(float4*)dst = a;
+      else {
+        dst[0] = a.x;
+        if (col + 1 < p.N) dst[1] = a.y;
+        if (col + 2 < p.N) dst[2] = a.z;
+        if (col + 3 < p.N) dst[3] = a.w;
+      }
+    }
+    return;
+  }
   const long coff = (long)z0 * p.sC_z0 + (long)z1 * p.sC_z1;
   const float* R = p.R ? p.R + (long)z0 * p.sR_z0 + (long)z1 * p.sR_z1 : nullptr;
   const bool need_b = p.bias_bn || p.r_up;
   const int rpb = p.rows_per_batch;
   const int b_first = need_b ? m0 / rpb : 0;          // a 256-row tile spans at most two samples when rpb >= BM
   const int b_edge = (b_first + 1) * rpb;
-  const int cq = (lane & 15) * 4;                     // this lane's 4 columns inside the wave tile
-  const int col = n0 + wn * 64 + cq;
   const bool full4 = col + 3 < p.N;
   float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias_n) {
@@ -645,7 +685,7 @@ static bool dma_eligible(const GemmParams& p) {
   if (!g_use_dma || p.dtype == DT_F32 || p.a_f32) return false;
   const int Ctot = p.C0 + p.C1;
   if (p.C0 % 64 != 0 || p.C1 % 64 != 0) return false;   // whole 64-channel K-tiles only (else v1)
-  if (p.M < 256 || p.N < 64) return false;              // small problems: v1's 64x64 tiles fill the chip better
+  if (p.M < 128 || p.N < 64) return false;              // small problems: v1's 64x64 tiles fill the chip better
   if (p.a_up && p.taps != 9) return false;
   if (p.c_nchw) return false;
   if (((long)p.M + 256) * std::max(p.lda0, p.lda1) * 2 >= (1L << 31)) return false;   // 32-bit offset arithmetic
@@ -656,18 +696,56 @@ static bool dma_eligible(const GemmParams& p) {
   return true;
 }
 
-template <typename TC, int MODE>
-static int launch_dma_mode(const GemmParams& p, hipStream_t stream) {
-  constexpr int BM = 256, BN = 128;
-  constexpr int smem = 3 * (BM + BN) * 128;
+// split-K second pass: sum the partial tiles in a fixed order (bitwise reproducible) and apply the epilogue
+template <typename TC>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const int nsplit) {
+  const long total = (long)p.M * p.N;
+  const int HW = p.H * p.W;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(idx / p.N), col = (int)(idx - (long)row * p.N);
+    float val = 0.f;
+    for (int k = 0; k < nsplit; ++k) val += ((const float*)p.ws)[(long)k * total + idx];
+    const int bidx = row / p.rows_per_batch;
+    long rrow = row;
+    if (p.r_up) {
+      const int rem = row - bidx * HW;
+      const int y = rem / p.W, x = rem - y * p.W;
+      rrow = ((long)bidx * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
+    }
+    if (p.bias_m) val += p.bias_m[row];
+    if (p.bias_n) val += p.bias_n[col];
+    if (p.bias_bn) val += p.bias_bn[(long)bidx * p.ld_bn + col];
+    if (p.R) val += p.R[rrow * p.ldr + col];
+    val *= p.alpha;
+    if (p.c_f32) ((float*)p.C)[(long)row * p.ldc + col] = val;
+    else ((TC*)p.C)[(long)row * p.ldc + col] = from_f32<TC>(val);
+  }
+}
+
+static bool g_splitk = true;
+void set_gemm_splitk(bool on) { g_splitk = on; }
+static int g_dma_geom = 0;   // 0 auto, 1 force 256x128x3, 2 force 128x128x2
+void set_gemm_geom(int v) { g_dma_geom = v; }
+
+template <typename TC, int MODE, int BM, int BN, int NST>
+static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
+  constexpr int smem = NST * (BM + BN) * 128;
+  constexpr int threads = (BM / 64) * (BN / 64) * 64;
   static bool attr_set = false;
-  auto kern = gemm_dma_kernel<TC, BM, BN, MODE>;
+  auto kern = gemm_dma_kernel<TC, BM, BN, MODE, NST>;
   if (!attr_set) {
     T2P_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  dim3 grid(tiles_m * tiles_n, p.nz0 * p.nz1);
+  // split-K when the tile grid cannot fill the chip and the K loop is long (low-resolution levels)
+  int nsplit = 1;
+  const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps;
+  if (g_splitk && p.ws && p.nz0 * p.nz1 == 1 && tiles_m * tiles_n < 192 && nk >= 16) {
+    nsplit = std::min(std::min(nk / 4, (384 + tiles_m * tiles_n - 1) / (tiles_m * tiles_n)), 32);
+    while (nsplit > 1 && (size_t)nsplit * p.M * p.N * 4 > p.ws_bytes) --nsplit;
+  }
+  dim3 grid(tiles_m * tiles_n, p.nz0 * p.nz1, nsplit);
   ProfRec rec;
   if (g_prof_on) {
     T2P_HIP_CHECK(hipEventCreate(&rec.a));
@@ -676,13 +754,27 @@ static int launch_dma_mode(const GemmParams& p, hipStream_t stream) {
     rec.kind = p.taps == 9 ? 0 : 1;
     T2P_HIP_CHECK(hipEventRecord(rec.a, stream));
   }
-  hipLaunchKernelGGL(kern, grid, dim3(512), smem, stream, p, tiles_m, tiles_n, g_dbg);
+  hipLaunchKernelGGL(kern, grid, dim3(threads), smem, stream, p, tiles_m, tiles_n, g_dbg);
+  if (nsplit > 1) {
+    const long total = (long)p.M * p.N;
+    const int g = (int)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel<TC>, dim3(g), dim3(256), 0, stream, p, nsplit);
+  }
   if (g_prof_on) {
     T2P_HIP_CHECK(hipEventRecord(rec.b, stream));
     g_prof.push_back(rec);
   }
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
+}
+
+template <typename TC, int MODE>
+static int launch_dma_mode(const GemmParams& p, hipStream_t stream) {
+  bool small = p.M < 256;             // 128x128 only for short problems (256x128 measured 15-20 % faster otherwise)
+  if (g_dma_geom == 1) small = false;
+  if (g_dma_geom == 2) small = true;
+  if (small) return launch_dma_geom<TC, MODE, 128, 128, 2>(p, stream);
+  return launch_dma_geom<TC, MODE, 256, 128, 3>(p, stream);
 }
 
 template <typename TC>

@@ -174,11 +174,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormApplyArgs a) {
     sh[k] = bv[k] - st[0] * sc[k];
   }
   TO* out = (TO*)a.out + (long)b * HWo * C + c;
+  TO* raw = a.raw_out ? (TO*)a.raw_out + (long)b * HWo * C + c : nullptr;
   const int p_lo = blockIdx.x * GNA_PIX_PER_BLOCK, p_hi = min(HWo, p_lo + GNA_PIX_PER_BLOCK);
   if (!a.down) {
 #pragma unroll 2
     for (int p = p_lo + po; p < p_hi; p += ppi) {
       const float4 t = *(const float4*)(src + (long)p * ld);
+      if (raw) store4<TO>(raw + (long)p * C, t.x, t.y, t.z, t.w);
       float y0 = t.x * sc[0] + sh[0], y1 = t.y * sc[1] + sh[1], y2 = t.z * sc[2] + sh[2], y3 = t.w * sc[3] + sh[3];
       if (a.silu) { y0 = silu_fast(y0); y1 = silu_fast(y1); y2 = silu_fast(y2); y3 = silu_fast(y3); }
       store4<TO>(out + (long)p * C, y0, y1, y2, y3);
@@ -210,6 +212,7 @@ int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s) {
   T2P_REQUIRE(a.x0 && a.stats && a.gamma && a.beta && a.out, "null pointer");
   T2P_REQUIRE(a.C0 % 4 == 0 && a.C1 % 4 == 0 && C % a.G == 0, "channel constraints");
   T2P_REQUIRE(!a.down || (a.H % 2 == 0 && a.W % 2 == 0), "down-sampling needs even H, W");
+  T2P_REQUIRE(!(a.down && a.raw_out), "raw copy is not produced together with down-sampling");
   const int HWo = (a.down ? a.H / 2 : a.H) * (a.down ? a.W / 2 : a.W);
   dim3 grid((HWo + GNA_PIX_PER_BLOCK - 1) / GNA_PIX_PER_BLOCK, a.B, (C + 1023) / 1024);
   switch (a.dtype) {
@@ -381,7 +384,8 @@ int launch_geglu(const float* u, void* out, int dtype, long rows, int inner, hip
 }
 
 // ================================== 2x2 mean pooling ===================================================
-__global__ __launch_bounds__(256) void pool2x2_kernel(const float* x, float* out, int B, int H, int W, int C) {
+template <typename TO>
+__global__ __launch_bounds__(256) void pool2x2_kernel(const float* x, TO* out, int B, int H, int W, int C) {
   const int nvec = C >> 2, Ho = H >> 1, Wo = W >> 1;
   const long total = (long)B * Ho * Wo * nvec;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -394,14 +398,20 @@ __global__ __launch_bounds__(256) void pool2x2_kernel(const float* x, float* out
     const float4 a = *(const float4*)p, b1 = *(const float4*)(p + C);
     const float4 c = *(const float4*)(p + (long)W * C), d = *(const float4*)(p + (long)W * C + C);
     // torch.mean over the (2, 2) window: sum in row-major window order, then divide
-    *(float4*)(out + pix * C + v * 4) = make_float4((a.x + b1.x + c.x + d.x) * 0.25f, (a.y + b1.y + c.y + d.y) * 0.25f,
-                                                     (a.z + b1.z + c.z + d.z) * 0.25f, (a.w + b1.w + c.w + d.w) * 0.25f);
+    store4<TO>(out + pix * C + v * 4, (a.x + b1.x + c.x + d.x) * 0.25f, (a.y + b1.y + c.y + d.y) * 0.25f,
+               (a.z + b1.z + c.z + d.z) * 0.25f, (a.w + b1.w + c.w + d.w) * 0.25f);
   }
 }
 
-int launch_pool2x2(const float* x, float* out, int B, int H, int W, int C, hipStream_t s) {
+int launch_pool2x2(const float* x, void* out, int dtype, int B, int H, int W, int C, hipStream_t s) {
   T2P_REQUIRE(x && out && C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "pool2x2 arguments");
-  hipLaunchKernelGGL(pool2x2_kernel, dim3(ew_grid((long)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, s, x, out, B, H, W, C);
+  dim3 grid(ew_grid((long)B * (H / 2) * (W / 2) * (C / 4)));
+  switch (dtype) {
+    case DT_F32: hipLaunchKernelGGL(pool2x2_kernel<float>, grid, dim3(256), 0, s, x, (float*)out, B, H, W, C); break;
+    case DT_BF16: hipLaunchKernelGGL(pool2x2_kernel<bf16_t>, grid, dim3(256), 0, s, x, (bf16_t*)out, B, H, W, C); break;
+    case DT_F16: hipLaunchKernelGGL(pool2x2_kernel<f16_t>, grid, dim3(256), 0, s, x, (f16_t*)out, B, H, W, C); break;
+    default: set_last_error("pool2x2: bad dtype"); return T2P_ERR_INVALID;
+  }
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }

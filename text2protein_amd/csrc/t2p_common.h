@@ -116,11 +116,16 @@ struct GemmParams {
   int c_nchw = 0;            // store C as [batch][N][H*W] fp32, scaled by row_scale[batch]
   const float* row_scale = nullptr;
   int dtype = DT_F32;        // compute dtype of A (if !a_f32), Bw and C (if !c_f32)
+  void* ws = nullptr;        // optional split-K workspace (fp32 partial tiles)
+  size_t ws_bytes = 0;
 };
 
 int launch_gemm(const GemmParams& p, hipStream_t stream);
 void set_gemm_dma(bool on);
 void set_gemm_debug(int v);
+void set_gemm_geom(int v);
+void set_gemm_splitk(bool on);
+extern bool g_raw_copies;   // engine: feed 1x1 shortcut / proj_out GEMMs with compute-dtype copies
 void profile_begin();
 int profile_end(double out[2][3]);
 

@@ -27,6 +27,8 @@ struct GroupNormApplyArgs {
   int down = 0;                        // 2x2 mean of the activated map (layers.py:185-188)
   void* out = nullptr;                 // [B][H'*W'][C] in `dtype`
   int dtype = DT_F32;
+  void* raw_out = nullptr;             // optional: un-normalised x (concat of both sources) in `dtype`,
+                                       // same resolution as the input (not with `down`)
 };
 int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s);
 
@@ -42,7 +44,7 @@ int launch_softmax(const float* S, long lds, void* P, long ldp, int dtype, long 
 int launch_geglu(const float* u, void* out, int dtype, long rows, int inner, hipStream_t s);
 
 // ---- 2x2 mean pooling of an NHWC fp32 map (skip branch of a down block, layers.py:309-311) ------
-int launch_pool2x2(const float* x, float* out, int B, int H, int W, int C, hipStream_t s);
+int launch_pool2x2(const float* x, void* out, int dtype, int B, int H, int W, int C, hipStream_t s);
 
 // ---- NCHW fp32 (B,C,L,L) -> NHWC fp32 [B][L*L][Cpad], zero padded channels -----------------------
 int launch_nchw_to_nhwc(const float* x, float* out, int B, int C, int HW, int Cpad, hipStream_t s);
