@@ -175,7 +175,9 @@ def test_geglu(lib):
 
 
 @pytest.mark.parametrize("dt", [0, 1, 2])
-@pytest.mark.parametrize("B,heads,nq,nk,d", [(2, 4, 64, 64, 16), (1, 8, 256, 77, 64), (2, 1, 64, 64, 256), (2, 2, 4, 3, 32)])
+@pytest.mark.parametrize("B,heads,nq,nk,d", [(2, 4, 64, 64, 16), (1, 8, 256, 77, 64), (2, 1, 64, 64, 256), (2, 2, 4, 3, 32),
+                                             (2, 8, 1024, 1024, 64), (1, 4, 300, 512, 128), (3, 8, 256, 256, 32),
+                                             (2, 8, 16, 16, 64), (1, 2, 130, 65, 64)])
 def test_attention(lib, dt, B, heads, nq, nk, d):
     g = torch.Generator().manual_seed(nq + nk)
     C_ = heads * d

@@ -8,7 +8,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libt2p_hip.so")
-SOURCES = ["gemm.hip", "kernels.hip", "engine.cpp", "capi.cpp"]
+SOURCES = ["gemm.hip", "kernels.hip", "attention.hip", "engine.cpp", "capi.cpp"]
 HEADERS = ["t2p_common.h", "t2p_kernels.h", "engine.h", os.path.join("..", "..", "include", "t2p.h")]
 ARCH = "gfx950"
 

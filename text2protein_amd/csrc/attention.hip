@@ -1,0 +1,265 @@
+// Fused multi-head attention (flash style) for gfx950: softmax(q k^T * scale) v without
+// materialising the score matrix.  Replaces, for 16-bit compute dtypes and head dims 32/64/128,
+// the einsum -> softmax -> einsum chain of CrossAttention.forward (reference model/attention.py:
+// 181-191) for both the self-attention (attn1) and the text cross-attention (attn2).
+//
+// Orientation: S^T = K Q^T, so the 32x32 MFMA accumulator has the QUERY on the lane and 16 keys in
+// the lane's registers (the other 16 keys of the tile sit in lane ^ 32).  The row softmax is then
+// 16 in-register operations plus ONE wavefront shuffle (xor 32) per statistic, and the
+// accumulator already is the B operand of the next product O^T = V^T P^T (k order permuted
+// consistently in both operands: element j of lane half h is key 16 s + 8 (j >> 2) + 4 h + (j & 3)),
+// whose A operand comes from the V^T tile the engine produces anyway.  O^T keeps the query on
+// the lane, so the online-softmax rescale is a per-lane scalar.
+//
+// One workgroup = 4 wavefronts x 32 queries; K and V^T tiles of 64 keys are staged
+// global -> registers -> LDS (padded rows: conflict-free ds_read_b128 / ds_read_b64),
+// double-buffered.
+#include "t2p_kernels.h"
+
+namespace t2p {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+template <typename TC> struct AMma;
+template <> struct AMma<bf16_t> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct AMma<f16_t> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+template <typename TC> __device__ inline uint32_t pack2(float a, float b);
+template <> __device__ inline uint32_t pack2<bf16_t>(float a, float b) {
+  return (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(b) << 16);
+}
+template <> __device__ inline uint32_t pack2<f16_t>(float a, float b) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  h2 v = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+struct FlashArgs {
+  const void* q; long ldq; long sq_b;       // [B][nq][ldq], head h at column h * D
+  const void* k; long ldk; long sk_b;       // [B][nk][ldk]
+  const void* vt; long ldvt; long svt_b;    // [B][heads * D][ldvt]
+  void* out; long ldo; long so_b;           // [B][nq][ldo]
+  int nq, nk;
+  float scale_log2e;                        // scale * log2(e)
+};
+
+template <typename TC, int D>
+__global__ __launch_bounds__(256) void attn_flash_kernel(const FlashArgs a) {
+  constexpr int BKV = 64;
+  constexpr int KS = D * 2 + 16;            // K tile row stride (bytes)
+  constexpr int VS = BKV * 2 + 8;           // V^T tile row stride (bytes)
+  constexpr int KBYTES = BKV * KS, VBYTES = D * VS;
+  constexpr int NS = D / 16;                // k-steps of the score product
+  constexpr int NT = D / 32;                // 32-row tiles of O^T
+  constexpr int KV = D / 32;                // staging vectors per thread for each of K and V^T
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][K tile | V^T tile]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const TC* Q = (const TC*)a.q + (long)b * a.sq_b + (long)head * D;
+  const TC* K = (const TC*)a.k + (long)b * a.sk_b + (long)head * D;
+  const TC* VT = (const TC*)a.vt + (long)b * a.svt_b + (long)head * D * a.ldvt;
+
+  // Q fragments (B operand of S^T = K Q^T): lane (query lr, half lh) holds Q[q][16 s + 8 lh .. + 7]
+  uint4 qf[NS];
+  {
+    const int qrow = q0 + lr;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      qf[s] = qrow < a.nq ? *(const uint4*)(Q + (long)qrow * a.ldq + 16 * s + 8 * lh) : make_uint4(0, 0, 0, 0);
+  }
+
+  // staging: K tile = 64 rows x (D/8) 16-byte chunks, V^T tile = D rows x 8 chunks
+  uint4 rk[KV], rv[KV];
+  auto gload = [&](int t) {
+    const int key0 = t * BKV;
+#pragma unroll
+    for (int i = 0; i < KV; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / (D / 8), ch = idx % (D / 8);
+      const int key = key0 + row;
+      rk[i] = key < a.nk ? *(const uint4*)(K + (long)key * a.ldk + ch * 8) : make_uint4(0, 0, 0, 0);
+      const int vrow = idx >> 3, vch = idx & 7;
+      const int kc = key0 + vch * 8;          // first key of this chunk
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (kc < a.nk) {
+        v = *(const uint4*)(VT + (long)vrow * a.ldvt + kc);
+        if (kc + 8 > a.nk) {                  // ragged tail: padding columns may hold anything
+          union { uint4 u; unsigned short e[8]; } x;
+          x.u = v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (kc + e >= a.nk) x.e[e] = 0;
+          v = x.u;
+        }
+      }
+      rv[i] = v;
+    }
+  };
+  auto sstore = [&](int buf) {
+    unsigned char* kb = smem + buf * (KBYTES + VBYTES);
+    unsigned char* vb = kb + KBYTES;
+#pragma unroll
+    for (int i = 0; i < KV; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / (D / 8), ch = idx % (D / 8);
+      *(uint4*)(kb + row * KS + ch * 16) = rk[i];
+      const int vrow = idx >> 3, vch = idx & 7;
+      uint2* dst = (uint2*)(vb + vrow * VS + vch * 16);     // rows are 8-byte aligned only
+      dst[0] = make_uint2(rv[i].x, rv[i].y);
+      dst[1] = make_uint2(rv[i].z, rv[i].w);
+    }
+  };
+
+  f32x16 o[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) o[t][v] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  const int ntile = (a.nk + BKV - 1) / BKV;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntile) gload(t + 1);
+    const unsigned char* kb = smem + buf * (KBYTES + VBYTES);
+    const unsigned char* vb = kb + KBYTES;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int kbase = t * BKV + sub * 32;
+      if (kbase >= a.nk) break;                                   // wave-uniform
+      // ---- S^T (32 keys x 32 queries) -------------------------------------------------------
+      f32x16 sacc;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) sacc[v] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const uint4 kf = *(const uint4*)(kb + (sub * 32 + lr) * KS + s * 32 + lh * 16);
+        AMma<TC>::run(kf, qf[s], sacc);
+      }
+      // ---- online softmax: this lane = query lr, registers = keys (v&3) + 8 (v>>2) + 4 lh ----
+      float mx = -INFINITY;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int key = kbase + (v & 3) + 8 * (v >> 2) + 4 * lh;
+        sacc[v] = key < a.nk ? sacc[v] * a.scale_log2e : -INFINITY;
+        mx = fmaxf(mx, sacc[v]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m, mx);                           // finite: every sub-tile entered has a valid key
+      const float alpha = __builtin_amdgcn_exp2f(m - m_new);      // exp2(-inf) = 0 on the first tile
+      float rs = 0.f;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        sacc[v] = __builtin_amdgcn_exp2f(sacc[v] - m_new);
+        rs += sacc[v];
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      l = l * alpha + rs;
+      m = m_new;
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) o[tt][v] *= alpha;
+      // ---- O^T += V^T P^T: P registers 8 ks .. 8 ks + 7 are the B fragment of k-step ks --------
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint4 pf;
+        pf.x = pack2<TC>(sacc[8 * ks + 0], sacc[8 * ks + 1]);
+        pf.y = pack2<TC>(sacc[8 * ks + 2], sacc[8 * ks + 3]);
+        pf.z = pack2<TC>(sacc[8 * ks + 4], sacc[8 * ks + 5]);
+        pf.w = pack2<TC>(sacc[8 * ks + 6], sacc[8 * ks + 7]);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          const unsigned char* vr = vb + (tt * 32 + lr) * VS + (sub * 32 + 16 * ks + 4 * lh) * 2;
+          const uint2 v0 = *(const uint2*)vr;            // keys 16 ks + 4 lh + 0..3
+          const uint2 v1 = *(const uint2*)(vr + 16);     // keys 16 ks + 8 + 4 lh + 0..3
+          AMma<TC>::run(make_uint4(v0.x, v0.y, v1.x, v1.y), pf, o[tt]);
+        }
+      }
+    }
+    if (t + 1 < ntile) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- O[q][dv] = O^T / l ----------------------------------------------------------------------
+  const int qrow = q0 + lr;
+  if (qrow < a.nq) {
+    const float inv = 1.f / l;
+    TC* orow = (TC*)a.out + (long)b * a.so_b + (long)qrow * a.ldo + (long)head * D;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = tt * 32 + 8 * g + 4 * lh;
+        uint2 u;
+        u.x = pack2<TC>(o[tt][4 * g + 0] * inv, o[tt][4 * g + 1] * inv);
+        u.y = pack2<TC>(o[tt][4 * g + 2] * inv, o[tt][4 * g + 3] * inv);
+        *(uint2*)(orow + dv) = u;
+      }
+  }
+}
+
+template <typename TC, int D>
+static int launch_flash_t(const FlashArgs& a, int B, int heads, hipStream_t s) {
+  constexpr int smem = 2 * (64 * (D * 2 + 16) + D * (64 * 2 + 8));
+  static bool attr_set = false;
+  auto kern = attn_flash_kernel<TC, D>;
+  if (!attr_set) {
+    T2P_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  dim3 grid((a.nq + 127) / 128, heads, B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+bool attention_flash_eligible(int dtype, int d, long ldq, long ldk, long ldvt, long ldo) {
+  if (dtype == DT_F32) return false;
+  if (d != 32 && d != 64 && d != 128) return false;
+  return ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0;
+}
+
+int launch_attention_flash(int dtype, const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt,
+                           void* out, int B, int heads, int nq, int nk, int d, float scale, hipStream_t s) {
+  T2P_REQUIRE(attention_flash_eligible(dtype, d, ldq, ldk, ldvt, (long)heads * d), "flash attention: unsupported shape");
+  T2P_REQUIRE(q && k && vt && out && B > 0 && heads > 0 && nq > 0 && nk > 0, "flash attention arguments");
+  T2P_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 8) == 0,
+              "flash attention: operands must be 16-byte aligned");
+  FlashArgs a;
+  a.q = q; a.ldq = ldq; a.sq_b = (long)nq * ldq;
+  a.k = k; a.ldk = ldk; a.sk_b = (long)nk * ldk;
+  a.vt = vt; a.ldvt = ldvt; a.svt_b = (long)heads * d * ldvt;
+  a.out = out; a.ldo = (long)heads * d; a.so_b = (long)nq * heads * d;
+  a.nq = nq; a.nk = nk;
+  a.scale_log2e = scale * 1.44269504088896340736f;
+#define T2P_FLASH(TC, DD) return launch_flash_t<TC, DD>(a, B, heads, s)
+  if (dtype == DT_BF16) {
+    if (d == 32) T2P_FLASH(bf16_t, 32);
+    if (d == 64) T2P_FLASH(bf16_t, 64);
+    T2P_FLASH(bf16_t, 128);
+  } else {
+    if (d == 32) T2P_FLASH(f16_t, 32);
+    if (d == 64) T2P_FLASH(f16_t, 64);
+    T2P_FLASH(f16_t, 128);
+  }
+#undef T2P_FLASH
+}
+
+}  // namespace t2p

@@ -218,6 +218,8 @@ int t2p_op_attention(int dtype, const void* q, int64_t ldq, const void* k, int64
   API_BEGIN
   T2P_REQUIRE(workspace && ((uintptr_t)workspace % 256) == 0, "workspace must be 256-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  if (g_flash_attention && attention_flash_eligible(dtype, d, ldq, ldk, ldvt, (long)heads * d))
+    return launch_attention_flash(dtype, q, ldq, k, ldk, vt, ldvt, out, batch, heads, nq, nk, d, scale, s);
   const long nkp = rup8(nk), rows = (long)batch * heads * nq;
   float* S = (float*)workspace;
   void* P = (char*)workspace + ((rows * nkp * 4 + 255) / 256) * 256;
@@ -312,6 +314,7 @@ int t2p_debug_set(int key, int value) {
   else if (key == 2) set_gemm_geom(value);
   else if (key == 3) set_gemm_splitk(value != 0);
   else if (key == 4) g_raw_copies = value != 0;
+  else if (key == 5) g_flash_attention = value != 0;
   else return T2P_ERR_INVALID;
   return T2P_OK;
 }

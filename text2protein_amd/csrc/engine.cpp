@@ -12,6 +12,7 @@
 namespace t2p {
 
 bool g_raw_copies = true;
+bool g_flash_attention = true;
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 const char* get_last_error() { return g_last_error.c_str(); }
@@ -591,6 +592,8 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
 int Engine::attention(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, int B,
                       int heads, int nq, int nk, int d, float scale, hipStream_t s) {
   const int dt = dtype();
+  if (g_flash_attention && attention_flash_eligible(dt, d, ldq, ldk, ldvt, (long)heads * d))
+    return launch_attention_flash(dt, q, ldq, k, ldk, vt, ldvt, out, B, heads, nq, nk, d, scale, s);
   const long nkp = (long)round_up((size_t)nk, 8);
   const long rows = (long)B * heads * nq;
   POOL_GET(S, float*, (size_t)rows * nkp * 4);

@@ -683,7 +683,6 @@ void set_gemm_debug(int v) { g_dbg = v; }
 
 static bool dma_eligible(const GemmParams& p) {
   if (!g_use_dma || p.dtype == DT_F32 || p.a_f32) return false;
-  const int Ctot = p.C0 + p.C1;
   if (p.C0 % 64 != 0 || p.C1 % 64 != 0) return false;   // whole 64-channel K-tiles only (else v1)
   if (p.M < 128 || p.N < 64) return false;              // small problems: v1's 64x64 tiles fill the chip better
   if (p.a_up && p.taps != 9) return false;

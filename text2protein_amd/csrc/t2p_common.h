@@ -125,6 +125,7 @@ void set_gemm_dma(bool on);
 void set_gemm_debug(int v);
 void set_gemm_geom(int v);
 void set_gemm_splitk(bool on);
+extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible
 extern bool g_raw_copies;   // engine: feed 1x1 shortcut / proj_out GEMMs with compute-dtype copies
 void profile_begin();
 int profile_end(double out[2][3]);
