@@ -172,24 +172,41 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
+        # dominant kernel = the LDS-DMA implicit-GEMM 3x3 convolution (gemm_dma_kernel, modes 1/2):
+        # every launch of one PC step timed with HIP events on the launch stream
         lib = load()
         check(lib.t2p_profile_begin())
         nprof = 1
         for _ in range(nprof):
             stepper.step(x, x_mean)
-        o = (C.c_double * 6)()
+        o = (C.c_double * 9)()
         check(lib.t2p_profile_end(o))
-        conv_ms, conv_fl, conv_n, g_ms, g_fl, g_n = list(o)
+        conv_ms, conv_fl, conv_n, g_ms, g_fl, g_n, c1_ms, c1_fl, c1_n = list(o)
         peak = MFMA_PEAK_TFLOPS[args.dtype]
+        if conv_n == 0:            # fp32 mode: every convolution runs on the register-staged exact-f32 kernel
+            conv_ms, conv_fl, conv_n, c1_ms, c1_fl, c1_n = c1_ms, c1_fl, c1_n, 0.0, 0.0, 0.0
+            kname = "gemm_kernel<float> (implicit-GEMM 3x3 convolution, v_mfma_f32_32x32x2_f32)"
+        else:
+            kname = "gemm_dma_kernel (LDS-DMA implicit-GEMM 3x3 convolution)"
         ach = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        traffic = None
+        tfile = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        if tfile and args.workload == "cfg2" and args.dtype == "f16" and B == 32:
+            # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+            # (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction; profiles/README.md)
+            t = json.load(open(tfile[-1]))
+            for k, v in t.items():
+                if k.startswith("gemm_dma_kernel") and ", 1, " in k:
+                    traffic = v["hbm_bytes_per_launch"]
         out["roofline"] = {
-            "bound": "mfma", "kernel": "gemm_kernel (implicit-GEMM 3x3 convolution launches)",
-            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "bound": "mfma", "kernel": kname,
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
             "launches_per_step": conv_n / nprof, "avg_launch_ms": conv_ms / max(conv_n, 1),
             "algorithmic_gflop_per_launch": conv_fl / max(conv_n, 1) / 1e9,
             "share_of_step_ms": conv_ms / nprof,
             "other_gemm": {"achieved": g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0, "launches_per_step": g_n / nprof,
                            "share_of_step_ms": g_ms / nprof, "frac": (g_fl / (g_ms * 1e-3) / 1e12 / peak) if g_ms > 0 else 0.0},
+            "conv_on_v1_kernel": {"launches_per_step": c1_n / nprof, "share_of_step_ms": c1_ms / nprof},
         }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, sd, ctx_cpu, N)

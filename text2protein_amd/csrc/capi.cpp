@@ -324,13 +324,13 @@ int t2p_profile_begin(void) {
   return T2P_OK;
 }
 
-int t2p_profile_end(double* out6) {
+int t2p_profile_end(double* out9) {
   API_BEGIN
-  T2P_REQUIRE(out6, "null argument");
-  double o[2][3];
+  T2P_REQUIRE(out9, "null argument");
+  double o[3][3];
   T2P_TRY(profile_end(o));
-  for (int k = 0; k < 2; ++k)
-    for (int j = 0; j < 3; ++j) out6[k * 3 + j] = o[k][j];
+  for (int k = 0; k < 3; ++k)
+    for (int j = 0; j < 3; ++j) out9[k * 3 + j] = o[k][j];
   return T2P_OK;
   API_END
 }

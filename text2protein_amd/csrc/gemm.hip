@@ -634,10 +634,12 @@ void profile_begin() {
   g_prof.clear();
   g_prof_on = true;
 }
-// out[kind][0..2] = {milliseconds, flops, launches}; kind 0 = 3x3 convolution, 1 = other GEMMs
-int profile_end(double out[2][3]) {
+// out[kind][0..2] = {milliseconds, flops, launches}; kind 0 = 3x3 convolutions on the LDS-DMA
+// kernel (the dominant kernel), 1 = other GEMMs, 2 = 3x3 convolutions on the register-staged kernel
+// (pre_conv in fp32, the 5-channel head, tiny maps)
+int profile_end(double out[3][3]) {
   g_prof_on = false;
-  for (int k = 0; k < 2; ++k) out[k][0] = out[k][1] = out[k][2] = 0;
+  for (int k = 0; k < 3; ++k) out[k][0] = out[k][1] = out[k][2] = 0;
   for (ProfRec& r : g_prof) {
     T2P_HIP_CHECK(hipEventSynchronize(r.b));
     float ms = 0.f;
@@ -664,7 +666,7 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     T2P_HIP_CHECK(hipEventCreate(&rec.a));
     T2P_HIP_CHECK(hipEventCreate(&rec.b));
     rec.flops = 2.0 * p.M * p.N * (double)p.taps * (p.C0 + p.C1) * p.nz0 * p.nz1;
-    rec.kind = p.taps == 9 ? 0 : 1;
+    rec.kind = p.taps == 9 ? 2 : 1;
     T2P_HIP_CHECK(hipEventRecord(rec.a, stream));
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);

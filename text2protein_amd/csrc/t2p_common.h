@@ -128,6 +128,6 @@ void set_gemm_splitk(bool on);
 extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible
 extern bool g_raw_copies;   // engine: feed 1x1 shortcut / proj_out GEMMs with compute-dtype copies
 void profile_begin();
-int profile_end(double out[2][3]);
+int profile_end(double out[3][3]);
 
 }  // namespace t2p

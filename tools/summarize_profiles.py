@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 outputs under gpurun_out/ into the committed summaries under profiles/.
+
+    python tools/summarize_profiles.py --tag r01 --stats gpurun_out/prof_r01 \
+        --fetch gpurun_out/pmc_r01_fetch --write gpurun_out/pmc_r01_write --steps-in-trace 7
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    return name.split("(")[0].replace("void t2p::", "").replace("t2p::", "")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--stats", required=True)
+    ap.add_argument("--fetch")
+    ap.add_argument("--write")
+    ap.add_argument("--steps-in-trace", type=int, required=True, help="PC steps executed under the profiler (warmup + timed + roofline leg)")
+    a = ap.parse_args()
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    ks = glob.glob(os.path.join(a.stats, "*", "*kernel_stats.csv"))[0]
+    shutil.copy(ks, os.path.join(out, f"{a.tag}_kernel_stats.csv"))
+    rows = list(csv.DictReader(open(glob.glob(os.path.join(a.stats, "*", "*kernel_trace.csv"))[0])))
+    per = collections.defaultdict(lambda: [0, 0.0])
+    tot = 0.0
+    for r in rows:
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        tot += d
+        key = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
+        per[key][0] += 1
+        per[key][1] += d
+    n = a.steps_in_trace
+    with open(os.path.join(out, f"{a.tag}_kernels_by_shape.md"), "w") as f:
+        f.write(f"# {a.tag}: kernels by launch shape (rocprofv3 --kernel-trace, {n} PC steps, cfg2 f16)\n\n")
+        f.write(f"GPU time per PC step: {tot / n / 1e3:.2f} ms\n\n| kernel | grid (workgroups) | launches/step | ms/step | avg us |\n|---|---|---|---|---|\n")
+        for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])[:45]:
+            f.write(f"| `{k[0]}` | {k[1]}x{k[2]}x{k[3]} | {v[0] / n:.1f} | {v[1] / n / 1e3:.2f} | {v[1] / v[0]:.1f} |\n")
+    traffic = {}
+    for kind, d in (("fetch", a.fetch), ("write", a.write)):
+        if not d:
+            continue
+        rr = list(csv.DictReader(open(glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0])))
+        acc = collections.defaultdict(lambda: [0, 0.0])
+        for r in rr:
+            nm = short(r["Kernel_Name"])
+            acc[nm][0] += 1
+            acc[nm][1] += float(r["Counter_Value"])
+        for nm, (c, v) in acc.items():
+            traffic.setdefault(nm, {})[kind + "_kb_per_launch"] = v / c
+            traffic[nm]["launches_" + kind] = c
+    if traffic:
+        # gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads -> doubled
+        # (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-B-per-lane stores.  Units: KiB.
+        for nm, t in traffic.items():
+            t["hbm_bytes_per_launch"] = (2.0 * t.get("fetch_kb_per_launch", 0.0) + t.get("write_kb_per_launch", 0.0)) * 1024.0
+        json.dump(traffic, open(os.path.join(out, f"{a.tag}_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    print("wrote summaries for", a.tag)
+
+
+if __name__ == "__main__":
+    main()
