@@ -11,6 +11,7 @@
 
 namespace t2p {
 
+bool g_fuse_gn_stats = true;
 bool g_raw_copies = true;
 bool g_flash_attention = true;
 static thread_local std::string g_last_error;
@@ -460,8 +461,18 @@ int Engine::gemm(GemmParams& p, hipStream_t s) {
   return launch_gemm(p, s);
 }
 
+int Engine::gemm_stats(GemmParams& p, float** cstats, hipStream_t s) {
+  *cstats = nullptr;
+  if (g_fuse_gn_stats && gemm_fuses_col_stats(p)) {
+    *cstats = (float*)pool_.get((size_t)(p.M / 64) * p.N * 2 * 4);
+    if (!*cstats) return T2P_ERR_HIP;
+    p.col_stats = *cstats;
+  }
+  return gemm(p, s);
+}
+
 int Engine::linear(const void* a, bool a_is_f32, const DevLinear& w, long rows, void* c, bool c_f32,
-                   const float* residual, float alpha, hipStream_t s, bool use_bias) {
+                   const float* residual, float alpha, hipStream_t s, bool use_bias, float** cstats) {
   GemmParams p;
   p.dtype = dtype();
   p.A0 = a; p.a_f32 = a_is_f32 || p.dtype == DT_F32; p.C0 = w.K; p.lda0 = w.K;
@@ -471,6 +482,7 @@ int Engine::linear(const void* a, bool a_is_f32, const DevLinear& w, long rows, 
   p.R = residual; p.ldr = w.N;
   p.alpha = alpha;
   p.C = c; p.c_f32 = c_f32; p.ldc = w.N;
+  if (cstats) return gemm_stats(p, cstats, s);
   return gemm(p, s);
 }
 
@@ -482,10 +494,17 @@ int Engine::group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps,
   a.x0 = x.p; a.x1 = x1 ? x1->p : nullptr; a.C0 = x.C; a.C1 = x1 ? x1->C : 0;
   a.B = B; a.HW = x.H * x.W; a.G = n.G; a.eps = eps;
   const int nparts = gn_num_chunks(a.HW) * ((C + 1023) / 1024);
-  POOL_GET(partial, float*, (size_t)B * nparts * n.G * 2 * 4);
   POOL_GET(stats, float*, (size_t)B * n.G * 2 * 4);
-  a.partial = partial; a.stats = stats;
-  T2P_TRY(launch_gn_stats(a, s));
+  float* partial = nullptr;
+  if (x.cstats && (!x1 || x1->cstats) && a.HW % 64 == 0) {
+    // statistics came with the producing GEMM's epilogue: no pass over the activation
+    T2P_TRY(launch_gn_finalize_cols(x.cstats, x1 ? x1->cstats : nullptr, a.C0, a.C1, B, a.HW, n.G, eps, stats, s));
+  } else {
+    partial = (float*)pool_.get((size_t)B * nparts * n.G * 2 * 4);
+    if (!partial) return T2P_ERR_HIP;
+    a.partial = partial; a.stats = stats;
+    T2P_TRY(launch_gn_stats(a, s));
+  }
   GroupNormApplyArgs g;
   g.x0 = a.x0; g.x1 = a.x1; g.C0 = a.C0; g.C1 = a.C1; g.B = B; g.H = x.H; g.W = x.W; g.G = n.G;
   g.stats = stats; g.gamma = n.gamma; g.beta = n.beta; g.silu = silu; g.down = down; g.dtype = dtype();
@@ -518,6 +537,7 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
   void* xraw = nullptr;
   const bool want_raw = g_raw_copies && L.has_conv2 && !L.down && dt != DT_F32;
   T2P_TRY(group_norm(x, skip, L.gn0, 1e-6f, 1, L.down, B, &a0, s, want_raw ? &xraw : nullptr));
+  float* h1_stats = nullptr;
   POOL_GET(h1, float*, (size_t)rows_out * Cout * 4);
   {
     GemmParams p;
@@ -526,13 +546,13 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     p.Bw = L.conv0.w; p.ldb = L.conv0.K; p.M = (int)rows_out; p.N = Cout;
     p.bias_n = L.conv0.b; p.bias_bn = tb_ + L.temb_off; p.ld_bn = tb_ld_; p.rows_per_batch = Ho * Wo;
     p.C = h1; p.c_f32 = 1; p.ldc = Cout;
-    T2P_TRY(gemm(p, s));
+    T2P_TRY(gemm_stats(p, &h1_stats, s));
   }
   pool_.put(a0);
-  Act h1a{h1, Cout, Ho, Wo};
+  Act h1a{h1, Cout, Ho, Wo, h1_stats};
   void* a1 = nullptr;
   T2P_TRY(group_norm(h1a, nullptr, L.gn1, 1e-6f, 1, 0, B, &a1, s));
-  pool_.put(h1);
+  free_act(h1a);
   // shortcut branch
   const float* r = x.p;
   float* rbuf = nullptr;
@@ -571,6 +591,7 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     T2P_REQUIRE(!skip && Cin == Cout, "identity shortcut needs equal channels");
   }
   POOL_GET(o, float*, (size_t)rows_out * Cout * 4);
+  float* o_stats = nullptr;
   {
     GemmParams p;
     p.dtype = dt; p.A0 = a1; p.a_f32 = dt == DT_F32; p.C0 = Cout; p.lda0 = Cout;
@@ -580,11 +601,11 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     p.R = r; p.ldr = Cout; p.r_up = r_up;
     p.alpha = cfg_.skip_rescale ? 0.70710678118654752440f : 1.f;
     p.C = o; p.c_f32 = 1; p.ldc = Cout;
-    T2P_TRY(gemm(p, s));
+    T2P_TRY(gemm_stats(p, &o_stats, s));
   }
   pool_.put(a1);
   pool_.put(rbuf);
-  *out = Act{o, Cout, Ho, Wo};
+  *out = Act{o, Cout, Ho, Wo, o_stats};
   return T2P_OK;
 }
 
@@ -651,9 +672,10 @@ int Engine::attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   pool_.put(qk);
   pool_.put(vt);
   POOL_GET(y, float*, (size_t)rows * C * 4);
-  T2P_TRY(linear(o, false, L.out, rows, y, true, x.p, cfg_.skip_rescale ? 0.70710678118654752440f : 1.f, s));
+  float* y_stats = nullptr;
+  T2P_TRY(linear(o, false, L.out, rows, y, true, x.p, cfg_.skip_rescale ? 0.70710678118654752440f : 1.f, s, true, &y_stats));
   pool_.put(o);
-  *out = Act{y, C, x.H, x.W};
+  *out = Act{y, C, x.H, x.W, y_stats};
   return T2P_OK;
 }
 
@@ -705,15 +727,16 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   }
   pool_.put(o);
   POOL_GET(y, float*, (size_t)rows * C * 4);
+  float* y_stats = nullptr;
   if (dt != DT_F32 && g_raw_copies) {
     T2P_TRY(launch_convert(t, ln, dt, rows * C, s));     // residual stream -> compute dtype (reuses the LN buffer)
-    T2P_TRY(linear(ln, false, L.proj_out, rows, y, true, x.p, 1.f, s));
+    T2P_TRY(linear(ln, false, L.proj_out, rows, y, true, x.p, 1.f, s, true, &y_stats));
   } else {
-    T2P_TRY(linear(t, true, L.proj_out, rows, y, true, x.p, 1.f, s));
+    T2P_TRY(linear(t, true, L.proj_out, rows, y, true, x.p, 1.f, s, true, &y_stats));
   }
   pool_.put(ln);
   pool_.put(t);
-  *out = Act{y, C, x.H, x.W};
+  *out = Act{y, C, x.H, x.W, y_stats};
   return T2P_OK;
 }
 
@@ -726,7 +749,7 @@ int Engine::run_stage(Stage& st, Act& h, const Act* skip, int B, hipStream_t s) 
     if (L.kind == 0) T2P_TRY(res_block(L, cur, i == 0 ? skip : nullptr, &nxt, B, s));
     else if (L.kind == 1) T2P_TRY(attn_block(L, cur, &nxt, B, s));
     else T2P_TRY(st_block(L, cur, &nxt, B, s));
-    if (own) pool_.put(cur.p);
+    if (own) free_act(cur);
     cur = nxt;
     own = true;
   }
@@ -825,14 +848,14 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
     T2P_REQUIRE(skip.C == st.skip_ch && skip.H == h.H, "skip stack mismatch");
     Act in = h;
     T2P_TRY(run_stage(st, h, &skip, B, s));
-    pool_.put(in.p);
-    pool_.put(skip.p);
+    free_act(in);
+    free_act(skip);
   }
   T2P_REQUIRE(hs.empty(), "skip stack not consumed");
   // head: GroupNorm -> SiLU -> conv3x3 (nf -> C), stored NCHW and divided by sigma[label]
   void* a = nullptr;
   T2P_TRY(group_norm(h, nullptr, head_norm_, 1e-6f, 1, 0, B, &a, s));
-  pool_.put(h.p);
+  free_act(h);
   {
     GemmParams p;
     p.dtype = dtype(); p.a_f32 = p.dtype == DT_F32; p.A0 = a; p.C0 = final_ch_; p.lda0 = final_ch_;

@@ -74,6 +74,7 @@ struct Stage {
 struct Act {  // an NHWC fp32 activation
   float* p = nullptr;
   int C = 0, H = 0, W = 0;
+  float* cstats = nullptr;   // optional per-64-row column sums of p (GemmParams::col_stats), for the consumer's GroupNorm
 };
 
 class Engine {
@@ -108,10 +109,13 @@ class Engine {
   int group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps, int silu, int down, int B, void** out,
                  hipStream_t s, void** raw_out = nullptr);
   int gemm(GemmParams& p, hipStream_t s);
+  // gemm() that also produces the output's GroupNorm column statistics when the kernel can (else *cstats = null)
+  int gemm_stats(GemmParams& p, float** cstats, hipStream_t s);
+  void free_act(Act& a) { pool_.put(a.p); pool_.put(a.cstats); a.p = nullptr; a.cstats = nullptr; }
   int attention(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, int B,
                 int heads, int nq, int nk, int d, float scale, hipStream_t s);
   int linear(const void* a, bool a_is_f32, const DevLinear& w, long rows, void* c, bool c_f32, const float* residual,
-             float alpha, hipStream_t s, bool use_bias = true);
+             float alpha, hipStream_t s, bool use_bias = true, float** cstats = nullptr);
 
   t2p_model_config cfg_;
   std::vector<ParamInfo> params_;

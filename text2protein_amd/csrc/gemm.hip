@@ -575,6 +575,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_dma_kernel(co
     }
   }
   const bool vec_ok = full4 && (p.ldc % 4 == 0) && (!R || p.ldr % 4 == 0) && (!p.bias_bn || p.ld_bn % 4 == 0);
+  float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f, cq0 = 0.f, cq1 = 0.f, cq2 = 0.f, cq3 = 0.f;   // column sums / sums of squares
 #pragma unroll 4
   for (int it = 0; it < 16; ++it) {
     const int rl = it * 4 + (lane >> 4);
@@ -601,6 +602,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_dma_kernel(co
         a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
       }
       a.x *= p.alpha; a.y *= p.alpha; a.z *= p.alpha; a.w *= p.alpha;
+      cs0 += a.x; cs1 += a.y; cs2 += a.z; cs3 += a.w;
+      cq0 += a.x * a.x; cq1 += a.y * a.y; cq2 += a.z * a.z; cq3 += a.w * a.w;
       if (p.c_f32) {
         *(float4*)((float*)p.C + coff + (long)row * p.ldc + col) = a;
       } else {
@@ -620,6 +623,20 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_dma_kernel(co
         if (p.c_f32) ((float*)p.C)[coff + (long)row * p.ldc + col + k] = val;
         else ((TC*)p.C)[coff + (long)row * p.ldc + col + k] = from_f32<TC>(val);
       }
+    }
+  }
+  // GroupNorm statistics of the tensor just produced (consumed by gn_finalize_cols_kernel): per
+  // 64-row chunk and column, sum and sum of squares of the final fp32 values.  Lanes l, l+16,
+  // l+32, l+48 hold the same 4 columns -> two wavefront shuffles; fixed order, reproducible.
+  if (p.col_stats) {
+    cs0 += __shfl_xor(cs0, 16, 64); cs1 += __shfl_xor(cs1, 16, 64); cs2 += __shfl_xor(cs2, 16, 64); cs3 += __shfl_xor(cs3, 16, 64);
+    cq0 += __shfl_xor(cq0, 16, 64); cq1 += __shfl_xor(cq1, 16, 64); cq2 += __shfl_xor(cq2, 16, 64); cq3 += __shfl_xor(cq3, 16, 64);
+    cs0 += __shfl_xor(cs0, 32, 64); cs1 += __shfl_xor(cs1, 32, 64); cs2 += __shfl_xor(cs2, 32, 64); cs3 += __shfl_xor(cs3, 32, 64);
+    cq0 += __shfl_xor(cq0, 32, 64); cq1 += __shfl_xor(cq1, 32, 64); cq2 += __shfl_xor(cq2, 32, 64); cq3 += __shfl_xor(cq3, 32, 64);
+    if (lane < 16 && vec_ok) {
+      float* dst = p.col_stats + ((long)((m0 + wm * 64) >> 6) * p.N + col) * 2;
+      *(float4*)dst = make_float4(cs0, cq0, cs1, cq1);
+      *(float4*)(dst + 4) = make_float4(cs2, cq2, cs3, cq3);
     }
   }
 }
@@ -727,6 +744,18 @@ static bool g_splitk = true;
 void set_gemm_splitk(bool on) { g_splitk = on; }
 static int g_dma_geom = 0;   // 0 auto, 1 force 256x128x3, 2 force 128x128x2
 void set_gemm_geom(int v) { g_dma_geom = v; }
+
+// true when launch_gemm(p) will run the LDS-DMA kernel without split-K and with a vector
+// epilogue, i.e. when a non-null p.col_stats will be filled
+bool gemm_fuses_col_stats(const GemmParams& p) {
+  if (!dma_eligible(p) || p.nz0 * p.nz1 != 1 || !p.c_f32) return false;
+  if (p.N % 4 != 0 || p.ldc % 4 != 0 || (p.R && p.ldr % 4 != 0) || (p.bias_bn && p.ld_bn % 4 != 0)) return false;
+  const int BM = (p.M < 256 || g_dma_geom == 2) && g_dma_geom != 1 ? 128 : 256;
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 127) / 128);
+  const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps;
+  if (g_splitk && tiles < 192 && nk >= 16) return false;     // split-K path writes raw partial tiles
+  return p.M % 64 == 0;
+}
 
 template <typename TC, int MODE, int BM, int BN, int NST>
 static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {

@@ -124,6 +124,42 @@ __global__ void gn_finalize_kernel(GroupNormArgs a, int nparts) {
   a.stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
 }
 
+// one wavefront per (sample, group): lanes stride over (chunk, channel) pairs, double accumulation
+__global__ __launch_bounds__(64) void gn_finalize_cols_kernel(const float* cs0, const float* cs1, int C0, int C1, int B, int HW,
+                                                              int G, float eps, float* stats) {
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int C = C0 + C1, cpg = C / G;
+  const int nchunk = HW >> 6;
+  const int lane = threadIdx.x;
+  double s = 0, q = 0;
+  const int total = nchunk * cpg;
+  for (int i = lane; i < total; i += 64) {
+    const int ch = i / cpg, c = g * cpg + (i - ch * cpg);
+    const float* src = c < C0 ? cs0 + ((long)(b * nchunk + ch) * C0 + c) * 2 : cs1 + ((long)(b * nchunk + ch) * C1 + (c - C0)) * 2;
+    s += src[0];
+    q += src[1];
+  }
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  if (lane == 0) {
+    const double n = (double)HW * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0) var = 0;
+    stats[2 * (b * G + g)] = (float)mean;
+    stats[2 * (b * G + g) + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+int launch_gn_finalize_cols(const float* cs0, const float* cs1, int C0, int C1, int B, int HW, int G, float eps, float* stats,
+                            hipStream_t s) {
+  T2P_REQUIRE(cs0 && stats && (C1 == 0) == (cs1 == nullptr), "gn_finalize_cols arguments");
+  T2P_REQUIRE(HW % 64 == 0 && (C0 + C1) % G == 0, "gn_finalize_cols needs 64-row chunks aligned to samples");
+  hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(B * G), dim3(64), 0, s, cs0, cs1, C0, C1, B, HW, G, eps, stats);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
 int launch_gn_stats(const GroupNormArgs& a, hipStream_t s) {
   const int C = a.C0 + a.C1;
   T2P_REQUIRE(a.x0 && a.partial && a.stats, "null pointer");

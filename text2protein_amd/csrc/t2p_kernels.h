@@ -18,6 +18,11 @@ struct GroupNormArgs {
 int gn_num_chunks(int HW);
 int launch_gn_stats(const GroupNormArgs& a, hipStream_t s);
 
+// statistics from per-chunk column sums written by the GEMM epilogue (GemmParams::col_stats):
+// cs0 / cs1 = [B * HW / 64][C0 or C1][2] for the two channel-concatenated sources
+int launch_gn_finalize_cols(const float* cs0, const float* cs1, int C0, int C1, int B, int HW, int G, float eps,
+                            float* stats, hipStream_t s);
+
 struct GroupNormApplyArgs {
   const float* x0 = nullptr; const float* x1 = nullptr;
   int C0 = 0, C1 = 0, B = 0, H = 0, W = 0, G = 0;
