@@ -12,6 +12,7 @@
 namespace t2p {
 
 bool g_fuse_gn_stats = true;
+bool g_fuse_geglu = true;
 bool g_raw_copies = true;
 bool g_flash_attention = true;
 static thread_local std::string g_last_error;
@@ -416,7 +417,24 @@ int Engine::finalize() {
       T2P_TRY(upload_linear(t + ".attn2.to_k.weight", "", ci, ctx, &l.a2_k));
       T2P_TRY(upload_linear(t + ".attn2.to_v.weight", "", ci, ctx, &l.a2_v));
       T2P_TRY(upload_linear(t + ".attn2.to_out.0.weight", t + ".attn2.to_out.0.bias", ci, ci, &l.a2_out));
-      T2P_TRY(upload_linear(t + ".ff.net.0.proj.weight", t + ".ff.net.0.proj.bias", 8 * ci, ci, &l.ff1));
+      {   // GEGLU projection with rows interleaved (value_j, gate_j) so the GEMM epilogue can gate in registers
+        const HostTensor* w = host(t + ".ff.net.0.proj.weight", {8 * ci, ci});
+        const HostTensor* b = host(t + ".ff.net.0.proj.bias", {8 * ci});
+        if (!w || !b) return T2P_ERR_STATE;
+        const int inner = 4 * ci;
+        std::vector<float> wi((size_t)8 * ci * ci), bi((size_t)8 * ci);
+        for (int j = 0; j < inner; ++j) {
+          std::copy(w->data.begin() + (size_t)j * ci, w->data.begin() + (size_t)(j + 1) * ci, wi.begin() + (size_t)(2 * j) * ci);
+          std::copy(w->data.begin() + (size_t)(inner + j) * ci, w->data.begin() + (size_t)(inner + j + 1) * ci,
+                    wi.begin() + (size_t)(2 * j + 1) * ci);
+          bi[2 * j] = b->data[j];
+          bi[2 * j + 1] = b->data[inner + j];
+        }
+        T2P_TRY(upload_matrix(pool_, wi, cfg_.compute_dtype, &l.ff1.w));
+        T2P_TRY(upload_f32(bi, &l.ff1.b));
+        l.ff1.N = 8 * ci;
+        l.ff1.K = ci;
+      }
       T2P_TRY(upload_linear(t + ".ff.net.2.weight", t + ".ff.net.2.bias", ci, 4 * ci, &l.ff2));
       T2P_TRY(upload_norm(t + ".norm1", ci, 1, &l.ln1));
       T2P_TRY(upload_norm(t + ".norm2", ci, 1, &l.ln2));
@@ -717,11 +735,19 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   // feed-forward with GEGLU
   T2P_TRY(launch_layernorm(t, L.ln3.gamma, L.ln3.beta, ln, dt, rows, C, 1e-5f, s));
   {
-    POOL_GET(u, float*, (size_t)rows * 8 * C * 4);
-    T2P_TRY(linear(ln, false, L.ff1, rows, u, true, nullptr, 1.f, s));
     POOL_GET(g, void*, (size_t)rows * 4 * C * es);
-    T2P_TRY(launch_geglu(u, g, dt, rows, 4 * C, s));
-    pool_.put(u);
+    GemmParams p;
+    p.dtype = dt; p.A0 = ln; p.a_f32 = dt == DT_F32; p.C0 = C; p.lda0 = C;
+    p.Bw = L.ff1.w; p.ldb = C; p.M = (int)rows; p.N = 8 * C; p.bias_n = L.ff1.b;
+    p.C = g; p.c_f32 = 0; p.ldc = 4 * C; p.geglu = 1;
+    if (g_fuse_geglu && gemm_fuses_geglu(p)) {
+      T2P_TRY(gemm(p, s));                       // value * gelu(gate) in the GEMM epilogue
+    } else {
+      POOL_GET(u, float*, (size_t)rows * 8 * C * 4);
+      T2P_TRY(linear(ln, false, L.ff1, rows, u, true, nullptr, 1.f, s));
+      T2P_TRY(launch_geglu(u, g, dt, rows, 4 * C, s, 1));
+      pool_.put(u);
+    }
     T2P_TRY(linear(g, false, L.ff2, rows, t, true, t, 1.f, s));
     pool_.put(g);
   }

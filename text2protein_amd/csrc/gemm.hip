@@ -490,8 +490,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_dma_kernel(co
   }
 #define T2P_WAIT(N, FA, FB) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FB[0]), "+v"(FB[1]))
 #define T2P_MMA(FA, FB)                                                                            \
+  if (dbg & 32) __builtin_amdgcn_s_setprio(1);                                                     \
   _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)      \
-      Mma<TC>::run(__builtin_bit_cast(uint4, FA[i]), __builtin_bit_cast(uint4, FB[j]), acc[i][j]);
+      Mma<TC>::run(__builtin_bit_cast(uint4, FA[i]), __builtin_bit_cast(uint4, FB[j]), acc[i][j]); \
+  if (dbg & 32) __builtin_amdgcn_s_setprio(0);
     // The fragment reads start right after the barrier; the DMA of K-tile kt+2 (address VALU +
     // 6 buffer_load...lds) is issued between MFMA groups so that it overlaps the matrix pipe
     // instead of holding every wave of the workgroup in a VALU-only phase.
@@ -574,7 +576,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_dma_kernel(co
       if (col + 2 < p.N) bn.z = p.bias_n[col + 2];
     }
   }
-  const bool vec_ok = full4 && (p.ldc % 4 == 0) && (!R || p.ldr % 4 == 0) && (!p.bias_bn || p.ld_bn % 4 == 0);
+  const bool vec_ok = full4 && (p.ldc % 4 == 0 || p.geglu) && (!R || p.ldr % 4 == 0) && (!p.bias_bn || p.ld_bn % 4 == 0);
   float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f, cq0 = 0.f, cq1 = 0.f, cq2 = 0.f, cq3 = 0.f;   // column sums / sums of squares
 #pragma unroll 4
   for (int it = 0; it < 16; ++it) {
@@ -600,6 +602,17 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_dma_kernel(co
       if (R) {
         const float4 t = *(const float4*)(R + rrow * p.ldr + col);
         a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
+      if (p.geglu) {
+        // columns are interleaved (value_j, gate_j): out[row][col / 2 + {0, 1}] = value * gelu_erf(gate)
+        // (GEGLU.forward, reference model/attention.py:42-44), stored in the compute dtype
+        const float g0 = 0.5f * a.y * (1.f + erff(a.y * 0.70710678118654752440f));
+        const float g1 = 0.5f * a.w * (1.f + erff(a.w * 0.70710678118654752440f));
+        TC* dst = (TC*)p.C + coff + (long)row * p.ldc + (col >> 1);
+        union { TC e[2]; uint32_t u; } o;
+        o.e[0] = from_f32<TC>(a.x * g0); o.e[1] = from_f32<TC>(a.z * g1);
+        *(uint32_t*)dst = o.u;
+        continue;
       }
       a.x *= p.alpha; a.y *= p.alpha; a.z *= p.alpha; a.w *= p.alpha;
       cs0 += a.x; cs1 += a.y; cs2 += a.z; cs3 += a.w;
@@ -744,6 +757,16 @@ static bool g_splitk = true;
 void set_gemm_splitk(bool on) { g_splitk = on; }
 static int g_dma_geom = 0;   // 0 auto, 1 force 256x128x3, 2 force 128x128x2
 void set_gemm_geom(int v) { g_dma_geom = v; }
+
+// true when launch_gemm(p) with p.geglu set will apply the fused GEGLU epilogue
+bool gemm_fuses_geglu(const GemmParams& p) {
+  if (!dma_eligible(p) || p.nz0 * p.nz1 != 1 || p.c_f32 || p.R || p.bias_bn || p.bias_m) return false;
+  if (p.N % 4 != 0 || p.ldc % 2 != 0) return false;
+  const int BM = (p.M < 256 || g_dma_geom == 2) && g_dma_geom != 1 ? 128 : 256;
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 127) / 128);
+  const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps;
+  return !(g_splitk && tiles < 192 && nk >= 16);
+}
 
 // true when launch_gemm(p) will run the LDS-DMA kernel without split-K and with a vector
 // epilogue, i.e. when a non-null p.col_stats will be filled

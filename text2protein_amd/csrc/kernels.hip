@@ -393,26 +393,33 @@ int launch_softmax(const float* S, long lds, void* P, long ldp, int dtype, long 
 
 // ================================== GEGLU ============================================================
 template <typename TO>
-__global__ __launch_bounds__(256) void geglu_kernel(const float* u, TO* out, long rows, int inner) {
+__global__ __launch_bounds__(256) void geglu_kernel(const float* u, TO* out, long rows, int inner, int interleaved) {
   const int nvec = inner >> 2;
   const long total = rows * nvec;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const long r = idx / nvec;
     const int j = (int)(idx - r * nvec) * 4;
-    const float4 a = *(const float4*)(u + r * 2 * inner + j);
-    const float4 g = *(const float4*)(u + r * 2 * inner + inner + j);
+    float4 a, g;
+    if (interleaved) {   // (value_j, gate_j) pairs: the layout of the fused-epilogue weights
+      const float4 p0 = *(const float4*)(u + r * 2 * inner + 2 * j), p1 = *(const float4*)(u + r * 2 * inner + 2 * j + 4);
+      a = make_float4(p0.x, p0.z, p1.x, p1.z);
+      g = make_float4(p0.y, p0.w, p1.y, p1.w);
+    } else {
+      a = *(const float4*)(u + r * 2 * inner + j);
+      g = *(const float4*)(u + r * 2 * inner + inner + j);
+    }
     auto gelu = [](float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); };
     store4<TO>(out + r * inner + j, a.x * gelu(g.x), a.y * gelu(g.y), a.z * gelu(g.z), a.w * gelu(g.w));
   }
 }
 
-int launch_geglu(const float* u, void* out, int dtype, long rows, int inner, hipStream_t s) {
+int launch_geglu(const float* u, void* out, int dtype, long rows, int inner, hipStream_t s, int interleaved) {
   T2P_REQUIRE(u && out && inner % 4 == 0 && rows > 0, "geglu arguments");
   dim3 grid(ew_grid(rows * (inner / 4)));
   switch (dtype) {
-    case DT_F32: hipLaunchKernelGGL(geglu_kernel<float>, grid, dim3(256), 0, s, u, (float*)out, rows, inner); break;
-    case DT_BF16: hipLaunchKernelGGL(geglu_kernel<bf16_t>, grid, dim3(256), 0, s, u, (bf16_t*)out, rows, inner); break;
-    case DT_F16: hipLaunchKernelGGL(geglu_kernel<f16_t>, grid, dim3(256), 0, s, u, (f16_t*)out, rows, inner); break;
+    case DT_F32: hipLaunchKernelGGL(geglu_kernel<float>, grid, dim3(256), 0, s, u, (float*)out, rows, inner, interleaved); break;
+    case DT_BF16: hipLaunchKernelGGL(geglu_kernel<bf16_t>, grid, dim3(256), 0, s, u, (bf16_t*)out, rows, inner, interleaved); break;
+    case DT_F16: hipLaunchKernelGGL(geglu_kernel<f16_t>, grid, dim3(256), 0, s, u, (f16_t*)out, rows, inner, interleaved); break;
     default: set_last_error("geglu: bad dtype"); return T2P_ERR_INVALID;
   }
   T2P_HIP_CHECK(hipGetLastError());

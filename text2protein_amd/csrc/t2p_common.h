@@ -116,6 +116,7 @@ struct GemmParams {
   int c_nchw = 0;            // store C as [batch][N][H*W] fp32, scaled by row_scale[batch]
   const float* row_scale = nullptr;
   int dtype = DT_F32;        // compute dtype of A (if !a_f32), Bw and C (if !c_f32)
+  int geglu = 0;             // B rows interleaved (value_j, gate_j): C[row][j] = value * gelu(gate), N/2 columns
   float* col_stats = nullptr;  // optional [M/64][N][2]: per 64-row chunk column sum / sum of squares of C
   void* ws = nullptr;        // optional split-K workspace (fp32 partial tiles)
   size_t ws_bytes = 0;
@@ -123,11 +124,13 @@ struct GemmParams {
 
 int launch_gemm(const GemmParams& p, hipStream_t stream);
 bool gemm_fuses_col_stats(const GemmParams& p);
+bool gemm_fuses_geglu(const GemmParams& p);
 void set_gemm_dma(bool on);
 void set_gemm_debug(int v);
 void set_gemm_geom(int v);
 void set_gemm_splitk(bool on);
 extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible
+extern bool g_fuse_geglu;      // engine: GEGLU gating inside the ff1 GEMM epilogue
 extern bool g_fuse_gn_stats;   // engine: GroupNorm statistics from the producing GEMM epilogue
 extern bool g_raw_copies;   // engine: feed 1x1 shortcut / proj_out GEMMs with compute-dtype copies
 void profile_begin();

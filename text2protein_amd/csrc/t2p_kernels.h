@@ -46,7 +46,7 @@ int launch_softmax(const float* S, long lds, void* P, long ldp, int dtype, long 
                    hipStream_t s);
 
 // ---- GEGLU (attention.py:37-44): out[r][j] = u[r][j] * gelu_erf(u[r][inner + j]) ----------------
-int launch_geglu(const float* u, void* out, int dtype, long rows, int inner, hipStream_t s);
+int launch_geglu(const float* u, void* out, int dtype, long rows, int inner, hipStream_t s, int interleaved = 0);
 
 // ---- 2x2 mean pooling of an NHWC fp32 map (skip branch of a down block, layers.py:309-311) ------
 int launch_pool2x2(const float* x, void* out, int dtype, int B, int H, int W, int C, hipStream_t s);
