@@ -468,7 +468,7 @@ int Engine::finalize() {
 
 // ------------------------------------------------------------------------------------------------
 // every GEMM of the engine: lends the split-K workspace (fp32 partial tiles of low-resolution levels)
-int Engine::gemm(GemmParams& p, hipStream_t s) {
+int Engine::attach_ws(GemmParams& p) {
   if (!splitk_ws_) {
     splitk_ws_bytes_ = (size_t)64 << 20;
     splitk_ws_ = pool_.persistent(splitk_ws_bytes_);
@@ -476,11 +476,17 @@ int Engine::gemm(GemmParams& p, hipStream_t s) {
   }
   p.ws = splitk_ws_;
   p.ws_bytes = splitk_ws_bytes_;
+  return T2P_OK;
+}
+
+int Engine::gemm(GemmParams& p, hipStream_t s) {
+  T2P_TRY(attach_ws(p));
   return launch_gemm(p, s);
 }
 
 int Engine::gemm_stats(GemmParams& p, float** cstats, hipStream_t s) {
   *cstats = nullptr;
+  T2P_TRY(attach_ws(p));          // the fuse predicate depends on the split-K decision
   if (g_fuse_gn_stats && gemm_fuses_col_stats(p)) {
     *cstats = (float*)pool_.get((size_t)(p.M / 64) * p.N * 2 * 4);
     if (!*cstats) return T2P_ERR_HIP;
@@ -740,6 +746,7 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     p.dtype = dt; p.A0 = ln; p.a_f32 = dt == DT_F32; p.C0 = C; p.lda0 = C;
     p.Bw = L.ff1.w; p.ldb = C; p.M = (int)rows; p.N = 8 * C; p.bias_n = L.ff1.b;
     p.C = g; p.c_f32 = 0; p.ldc = 4 * C; p.geglu = 1;
+    T2P_TRY(attach_ws(p));
     if (g_fuse_geglu && gemm_fuses_geglu(p)) {
       T2P_TRY(gemm(p, s));                       // value * gelu(gate) in the GEMM epilogue
     } else {

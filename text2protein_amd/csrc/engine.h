@@ -109,6 +109,7 @@ class Engine {
   int group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps, int silu, int down, int B, void** out,
                  hipStream_t s, void** raw_out = nullptr);
   int gemm(GemmParams& p, hipStream_t s);
+  int attach_ws(GemmParams& p);
   // gemm() that also produces the output's GroupNorm column statistics when the kernel can (else *cstats = null)
   int gemm_stats(GemmParams& p, float** cstats, hipStream_t s);
   void free_act(Act& a) { pool_.put(a.p); pool_.put(a.cstats); a.p = nullptr; a.cstats = nullptr; }

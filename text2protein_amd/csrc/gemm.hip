@@ -297,16 +297,22 @@ static constexpr unsigned DMA_OOB = 0x80000000u;   // >= any num_records we acce
 
 // MODE 0: plain GEMM rows; 1: 3x3 convolution; 2: 3x3 convolution reading a half-resolution source
 //
-// Two geometries are instantiated:
-//   256 x 128, 8 wavefronts, 3-stage ring (144 KiB): one workgroup per CU, loads two K-tiles ahead
-//   128 x 128, 4 wavefronts, 2-stage ring ( 64 KiB): two workgroups per CU -- their barriers,
-//       prologues and epilogues overlap each other's MFMA phases
-template <typename TC, int BM, int BN, int MODE, int NST>
-__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_dma_kernel(const GemmParams p, const int tiles_m, const int tiles_n, const int dbg) {
+// Geometries (BM x BN block, WM x WN wavefronts, NST ring stages):
+//   256 x 128, 4 x 2 waves (64 x 64 each),  3 stages (144 KiB): loads two K-tiles ahead
+//   256 x 256, 2 x 4 waves (128 x 64 each), 2 stages (128 KiB): A fetched once for N = 256,
+//       0.75 fragment reads per MFMA, half the barriers per FLOP
+//   128 x 128, 2 x 2 waves (64 x 64 each),  2 stages ( 64 KiB): two workgroups per CU (short problems)
+template <int I> __device__ inline void lds_read_b128(u32x4_t& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(I * 4096));
+}
+
+template <typename TC, int BM, int BN, int WM, int WN, int MODE, int NST>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams p, const int tiles_m, const int tiles_n, const int dbg) {
   constexpr int BK = 64;
-  constexpr int WM = BM / 64, WN = BN / 64;           // wave grid
   constexpr int NW = WM * WN;
+  constexpr int TI = BM / WM / 32, TJ = BN / WN / 32;  // 32x32 MFMA tiles per wave
   static_assert(NW == 8 || NW == 4, "4 or 8 wavefronts");
+  static_assert((TI == 2 || TI == 4) && (TJ == 2 || TJ == 4) && TI * TJ <= 8, "wave tile");
   static_assert(NW * 16384 <= NST * (BM + BN) * 128, "epilogue staging must fit the ring");
   constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;  // DMA instructions per wave per K-tile (8 rows each)
   constexpr int STAGE = (BM + BN) * 128;
@@ -441,20 +447,20 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_dma_kernel(co
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-  // fragment read offsets: row (wm*64 + i*32 + lr), chunk (2 s + lh) ^ ((row >> 1) & 7)
-  // (the second 32-row tile of a wave is 32 rows = 4096 bytes further and has the same swizzle
-  // term, so it is reached through the ds_read immediate offset)
+  // fragment read offsets: row (wave row base + i*32 + lr), chunk (2 s + lh) ^ ((row >> 1) & 7)
+  // (the i-th 32-row tile of a wave is i * 4096 bytes further and has the same swizzle term,
+  // so it is reached through the ds_read immediate offset)
   unsigned a_fo[4], b_fo[4];
   {
-    const int ra = wm * 64 + lr, rb = wn * 64 + lr;
+    const int ra = wm * (BM / WM) + lr, rb = wn * (BN / WN) + lr;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       a_fo[s] = (unsigned)(ra * 128 + (((2 * s + lh) ^ ((ra >> 1) & 7)) << 4));
@@ -476,48 +482,49 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_dma_kernel(co
     // Fragment reads go through inline asm: hipcc would otherwise put `s_waitcnt vmcnt(0)` in
     // front of every ds_read that may alias an in-flight LDS-DMA write and drain the ring.  The
     // reads of k-step s+1 are in flight while the MFMAs of step s run (lgkmcnt counts LDS ops in
-    // order: <= 4 outstanding means step s has landed).
+    // order: <= TI + TJ outstanding means step s has landed).
     const unsigned st_off = lds_base + (unsigned)((kt % NST) * STAGE);
-    u32x4_t fa0[2], fb0[2], fa1[2], fb1[2];
+    u32x4_t fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
 #define T2P_RD(S, FA, FB)                                                                          \
   {                                                                                                \
     const unsigned aa = st_off + a_fo[S];                                                          \
     const unsigned ba = st_off + b_fo[S];                                                          \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(FA[0]) : "v"(aa));                                   \
-    asm volatile("ds_read_b128 %0, %1" : "=v"(FB[0]) : "v"(ba));                                   \
-    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(FA[1]) : "v"(aa));                       \
-    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(FB[1]) : "v"(ba));                       \
+    lds_read_b128<0>(FA[0], aa);                                                                   \
+    lds_read_b128<0>(FB[0], ba);                                                                   \
+    lds_read_b128<1>(FA[1], aa);                                                                   \
+    lds_read_b128<1>(FB[1], ba);                                                                   \
+    if constexpr (TI == 4) { lds_read_b128<2>(FA[2], aa); lds_read_b128<3>(FA[3], aa); }           \
+    if constexpr (TJ == 4) { lds_read_b128<2>(FB[2], ba); lds_read_b128<3>(FB[3], ba); }           \
   }
-#define T2P_WAIT(N, FA, FB) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FB[0]), "+v"(FB[1]))
+#define T2P_WAIT(N, FA, FB)                                                                                           \
+  if constexpr (TI == 2 && TJ == 2)                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FB[0]), "+v"(FB[1]) : "n"(N));              \
+  else if constexpr (TI == 4)                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(%6)"                                                                              \
+                 : "+v"(FA[0]), "+v"(FA[1]), "+v"(FA[2]), "+v"(FA[3]), "+v"(FB[0]), "+v"(FB[1]) : "n"(N));            \
+  else                                                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(%6)"                                                                              \
+                 : "+v"(FA[0]), "+v"(FA[1]), "+v"(FB[0]), "+v"(FB[1]), "+v"(FB[2]), "+v"(FB[3]) : "n"(N));
 #define T2P_MMA(FA, FB)                                                                            \
-  if (dbg & 32) __builtin_amdgcn_s_setprio(1);                                                     \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)      \
-      Mma<TC>::run(__builtin_bit_cast(uint4, FA[i]), __builtin_bit_cast(uint4, FB[j]), acc[i][j]); \
-  if (dbg & 32) __builtin_amdgcn_s_setprio(0);
-    // The fragment reads start right after the barrier; the DMA of K-tile kt+2 (address VALU +
-    // 6 buffer_load...lds) is issued between MFMA groups so that it overlaps the matrix pipe
-    // instead of holding every wave of the workgroup in a VALU-only phase.
+  _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < TJ; ++j)    \
+      Mma<TC>::run(__builtin_bit_cast(uint4, FA[i]), __builtin_bit_cast(uint4, FB[j]), acc[i][j]);
+    // The fragment reads start right after the barrier; the DMA of the next K-tile (address
+    // VALU + buffer_load...lds) is issued between MFMA groups so that it overlaps the matrix
+    // pipe instead of holding every wave of the workgroup in a VALU-only phase.
+    constexpr int NRD = TI + TJ;
     T2P_RD(0, fa0, fb0)
     T2P_RD(1, fa1, fb1)
-    T2P_WAIT(4, fa0, fb0);
+    T2P_WAIT(NRD, fa0, fb0)
     T2P_MMA(fa0, fb0)
     if (more) issue(kt + AHEAD, 0);
-    if (dbg & 16) {          // timing probe: half the fragment reads
-      T2P_WAIT(0, fa1, fb1);
-      T2P_MMA(fa1, fb1)
-      if (more) issue(kt + AHEAD, 1);
-      T2P_MMA(fa0, fb0)
-      T2P_MMA(fa1, fb1)
-      continue;
-    }
     T2P_RD(2, fa0, fb0)
-    T2P_WAIT(4, fa1, fb1);
+    T2P_WAIT(NRD, fa1, fb1)
     T2P_MMA(fa1, fb1)
     if (more) issue(kt + AHEAD, 1);
     T2P_RD(3, fa1, fb1)
-    T2P_WAIT(4, fa0, fb0);
+    T2P_WAIT(NRD, fa0, fb0)
     T2P_MMA(fa0, fb0)
-    T2P_WAIT(0, fa1, fb1);
+    T2P_WAIT(0, fa1, fb1)
     T2P_MMA(fa1, fb1)
 #undef T2P_RD
 #undef T2P_WAIT
@@ -526,132 +533,141 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void gemm_dma_kernel(co
 
   // ---- epilogue ----------------------------------------------------------------------------------
   // The accumulators (row-per-register, column-per-lane) are staged through this wave's private
-  // 16 KiB slice of the now idle LDS ring and read back row-contiguous, so that bias / residual
-  // loads and the output stores are 16-byte vectors covering whole 256-byte row segments (the
-  // per-lane dword stores of v1 are store-issue bound: 64 instructions per wave instead of 16).
+  // 16 KiB slice of the now idle LDS ring, 64 rows at a time, and read back row-contiguous, so
+  // that bias / residual loads and the output stores are 16-byte vectors covering whole 256-byte
+  // row segments (per-lane dword stores are store-issue bound: 64 instructions per wave, not 16).
   if ((dbg & 1) && acc[0][0][0] != 123.456f) return;
   __builtin_amdgcn_s_barrier();                       // every wave is done reading the last stage
   float* stg = (float*)(smem + wave * 16384);         // [64 rows][64 cols] fp32
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) stg[(i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 64 + j * 32 + lr] = acc[i][j][v];
-  // same-wave LDS write -> read: the compiler orders them (lgkmcnt); no barrier needed
-  const int cq = (lane & 15) * 4;                     // this lane's 4 columns inside the wave tile
-  const int col = n0 + wn * 64 + cq;
-  if (nsplit > 1) {                                   // raw partial sums -> workspace [split][M][N]
-    float* ws = (float*)p.ws + (long)ks * p.M * p.N;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int rl = it * 4 + (lane >> 4);
-      const int row = m0 + wm * 64 + rl;
-      if (row >= p.M || col >= p.N) continue;
-      const float4 a = *(const float4*)(stg + rl * 64 + cq);
-      float* dst = ws + (long)row * p.N + col;
-      if (col + 3 < p.N && (p.N & 3) == 0) *(float4*)dst = a;
-      else {
-        dst[0] = a.x;
-        if (col + 1 < p.N) dst[1] = a.y;
-        if (col + 2 < p.N) dst[2] = a.z;
-        if (col + 3 < p.N) dst[3] = a.w;
-      }
-    }
-    return;
-  }
   const long coff = (long)z0 * p.sC_z0 + (long)z1 * p.sC_z1;
   const float* R = p.R ? p.R + (long)z0 * p.sR_z0 + (long)z1 * p.sR_z1 : nullptr;
   const bool need_b = p.bias_bn || p.r_up;
   const int rpb = p.rows_per_batch;
-  const int b_first = need_b ? m0 / rpb : 0;          // a 256-row tile spans at most two samples when rpb >= BM
+  const int b_first = need_b ? m0 / rpb : 0;          // a BM-row tile spans at most two samples when rpb >= BM
   const int b_edge = (b_first + 1) * rpb;
-  const bool full4 = col + 3 < p.N;
-  float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias_n) {
-    if (full4) bn = *(const float4*)(p.bias_n + col);
-    else {
-      if (col < p.N) bn.x = p.bias_n[col];
-      if (col + 1 < p.N) bn.y = p.bias_n[col + 1];
-      if (col + 2 < p.N) bn.z = p.bias_n[col + 2];
-    }
-  }
-  const bool vec_ok = full4 && (p.ldc % 4 == 0 || p.geglu) && (!R || p.ldr % 4 == 0) && (!p.bias_bn || p.ld_bn % 4 == 0);
-  float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f, cq0 = 0.f, cq1 = 0.f, cq2 = 0.f, cq3 = 0.f;   // column sums / sums of squares
+  const int cq = (lane & 15) * 4;                     // this lane's 4 columns inside a 64-column slab
+  float* ws = nsplit > 1 ? (float*)p.ws + (long)ks * p.M * p.N : nullptr;
+
+#pragma unroll
+  for (int hi = 0; hi < TI / 2; ++hi)                 // 64-row slabs of the wave tile
+#pragma unroll
+    for (int hj = 0; hj < TJ / 2; ++hj) {             // 64-column slabs
+      if (hi + hj > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // previous slab fully read back
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int v = 0; v < 16; ++v)
+            stg[(i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 64 + j * 32 + lr] = acc[2 * hi + i][2 * hj + j][v];
+      // same-wave LDS write -> read: the compiler orders them (lgkmcnt); no barrier needed
+      const int row0 = m0 + wm * (BM / WM) + hi * 64;
+      const int col = n0 + wn * (BN / WN) + hj * 64 + cq;
+      if (ws) {                                       // split-K: raw partial sums -> workspace [split][M][N]
 #pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
-    const int rl = it * 4 + (lane >> 4);
-    const int row = m0 + wm * 64 + rl;
-    if (row >= p.M || col >= p.N) continue;
-    float4 a = *(const float4*)(stg + rl * 64 + cq);
-    int bidx = 0;
-    if (need_b) bidx = rpb >= BM ? b_first + (row >= b_edge ? 1 : 0) : row / rpb;
-    long rrow = row;
-    if (p.r_up) {
-      const int rem = row - bidx * HW;
-      const int y = rem / p.W, x = rem - y * p.W;
-      rrow = ((long)bidx * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
-    }
-    const float bm = p.bias_m ? p.bias_m[row] : 0.f;
-    a.x += bm + bn.x; a.y += bm + bn.y; a.z += bm + bn.z; a.w += bm + bn.w;
-    if (vec_ok) {
-      if (p.bias_bn) {
-        const float4 t = *(const float4*)(p.bias_bn + (long)bidx * p.ld_bn + col);
-        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-      }
-      if (R) {
-        const float4 t = *(const float4*)(R + rrow * p.ldr + col);
-        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-      }
-      if (p.geglu) {
-        // columns are interleaved (value_j, gate_j): out[row][col / 2 + {0, 1}] = value * gelu_erf(gate)
-        // (GEGLU.forward, reference model/attention.py:42-44), stored in the compute dtype
-        const float g0 = 0.5f * a.y * (1.f + erff(a.y * 0.70710678118654752440f));
-        const float g1 = 0.5f * a.w * (1.f + erff(a.w * 0.70710678118654752440f));
-        TC* dst = (TC*)p.C + coff + (long)row * p.ldc + (col >> 1);
-        union { TC e[2]; uint32_t u; } o;
-        o.e[0] = from_f32<TC>(a.x * g0); o.e[1] = from_f32<TC>(a.z * g1);
-        *(uint32_t*)dst = o.u;
+        for (int it = 0; it < 16; ++it) {
+          const int rl = it * 4 + (lane >> 4);
+          const int row = row0 + rl;
+          if (row >= p.M || col >= p.N) continue;
+          const float4 a = *(const float4*)(stg + rl * 64 + cq);
+          float* dst = ws + (long)row * p.N + col;
+          if (col + 3 < p.N && (p.N & 3) == 0) *(float4*)dst = a;
+          else {
+            dst[0] = a.x;
+            if (col + 1 < p.N) dst[1] = a.y;
+            if (col + 2 < p.N) dst[2] = a.z;
+            if (col + 3 < p.N) dst[3] = a.w;
+          }
+        }
         continue;
       }
-      a.x *= p.alpha; a.y *= p.alpha; a.z *= p.alpha; a.w *= p.alpha;
-      cs0 += a.x; cs1 += a.y; cs2 += a.z; cs3 += a.w;
-      cq0 += a.x * a.x; cq1 += a.y * a.y; cq2 += a.z * a.z; cq3 += a.w * a.w;
-      if (p.c_f32) {
-        *(float4*)((float*)p.C + coff + (long)row * p.ldc + col) = a;
-      } else {
-        TC* dst = (TC*)p.C + coff + (long)row * p.ldc + col;
-        union { TC e[4]; uint2 u; } o;
-        o.e[0] = from_f32<TC>(a.x); o.e[1] = from_f32<TC>(a.y); o.e[2] = from_f32<TC>(a.z); o.e[3] = from_f32<TC>(a.w);
-        *(uint2*)dst = o.u;
+      const bool full4 = col + 3 < p.N;
+      float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias_n) {
+        if (full4) bn = *(const float4*)(p.bias_n + col);
+        else {
+          if (col < p.N) bn.x = p.bias_n[col];
+          if (col + 1 < p.N) bn.y = p.bias_n[col + 1];
+          if (col + 2 < p.N) bn.z = p.bias_n[col + 2];
+        }
       }
-    } else {
-      float vals[4] = {a.x, a.y, a.z, a.w};
-      for (int k = 0; k < 4; ++k) {
-        if (col + k >= p.N) break;
-        float val = vals[k];
-        if (p.bias_bn) val += p.bias_bn[(long)bidx * p.ld_bn + col + k];
-        if (R) val += R[rrow * p.ldr + col + k];
-        val *= p.alpha;
-        if (p.c_f32) ((float*)p.C)[coff + (long)row * p.ldc + col + k] = val;
-        else ((TC*)p.C)[coff + (long)row * p.ldc + col + k] = from_f32<TC>(val);
+      const bool vec_ok = full4 && (p.ldc % 4 == 0 || p.geglu) && (!R || p.ldr % 4 == 0) && (!p.bias_bn || p.ld_bn % 4 == 0);
+      float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f, cq0 = 0.f, cq1 = 0.f, cq2 = 0.f, cq3 = 0.f;   // column sums / sums of squares
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int rl = it * 4 + (lane >> 4);
+        const int row = row0 + rl;
+        if (row >= p.M || col >= p.N) continue;
+        float4 a = *(const float4*)(stg + rl * 64 + cq);
+        int bidx = 0;
+        if (need_b) bidx = rpb >= BM ? b_first + (row >= b_edge ? 1 : 0) : row / rpb;
+        long rrow = row;
+        if (p.r_up) {
+          const int rem = row - bidx * HW;
+          const int y = rem / p.W, x = rem - y * p.W;
+          rrow = ((long)bidx * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
+        }
+        const float bm = p.bias_m ? p.bias_m[row] : 0.f;
+        a.x += bm + bn.x; a.y += bm + bn.y; a.z += bm + bn.z; a.w += bm + bn.w;
+        if (vec_ok) {
+          if (p.bias_bn) {
+            const float4 t = *(const float4*)(p.bias_bn + (long)bidx * p.ld_bn + col);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+          }
+          if (R) {
+            const float4 t = *(const float4*)(R + rrow * p.ldr + col);
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+          }
+          if (p.geglu) {
+            // columns are interleaved (value_j, gate_j): out[row][col / 2 + {0, 1}] = value * gelu_erf(gate)
+            // (GEGLU.forward, reference model/attention.py:42-44), stored in the compute dtype
+            const float g0 = 0.5f * a.y * (1.f + erff(a.y * 0.70710678118654752440f));
+            const float g1 = 0.5f * a.w * (1.f + erff(a.w * 0.70710678118654752440f));
+            TC* dst = (TC*)p.C + coff + (long)row * p.ldc + (col >> 1);
+            union { TC e[2]; uint32_t u; } o;
+            o.e[0] = from_f32<TC>(a.x * g0); o.e[1] = from_f32<TC>(a.z * g1);
+            *(uint32_t*)dst = o.u;
+            continue;
+          }
+          a.x *= p.alpha; a.y *= p.alpha; a.z *= p.alpha; a.w *= p.alpha;
+          cs0 += a.x; cs1 += a.y; cs2 += a.z; cs3 += a.w;
+          cq0 += a.x * a.x; cq1 += a.y * a.y; cq2 += a.z * a.z; cq3 += a.w * a.w;
+          if (p.c_f32) {
+            *(float4*)((float*)p.C + coff + (long)row * p.ldc + col) = a;
+          } else {
+            TC* dst = (TC*)p.C + coff + (long)row * p.ldc + col;
+            union { TC e[4]; uint2 u; } o;
+            o.e[0] = from_f32<TC>(a.x); o.e[1] = from_f32<TC>(a.y); o.e[2] = from_f32<TC>(a.z); o.e[3] = from_f32<TC>(a.w);
+            *(uint2*)dst = o.u;
+          }
+        } else {
+          float vals[4] = {a.x, a.y, a.z, a.w};
+          for (int k = 0; k < 4; ++k) {
+            if (col + k >= p.N) break;
+            float val = vals[k];
+            if (p.bias_bn) val += p.bias_bn[(long)bidx * p.ld_bn + col + k];
+            if (R) val += R[rrow * p.ldr + col + k];
+            val *= p.alpha;
+            if (p.c_f32) ((float*)p.C)[coff + (long)row * p.ldc + col + k] = val;
+            else ((TC*)p.C)[coff + (long)row * p.ldc + col + k] = from_f32<TC>(val);
+          }
+        }
+      }
+      // GroupNorm statistics of the tensor just produced (consumed by gn_finalize_cols_kernel): per
+      // 64-row chunk and column, sum and sum of squares of the final fp32 values.  Lanes l, l+16,
+      // l+32, l+48 hold the same 4 columns -> two wavefront shuffles; fixed order, reproducible.
+      if (p.col_stats) {
+        cs0 += __shfl_xor(cs0, 16, 64); cs1 += __shfl_xor(cs1, 16, 64); cs2 += __shfl_xor(cs2, 16, 64); cs3 += __shfl_xor(cs3, 16, 64);
+        cq0 += __shfl_xor(cq0, 16, 64); cq1 += __shfl_xor(cq1, 16, 64); cq2 += __shfl_xor(cq2, 16, 64); cq3 += __shfl_xor(cq3, 16, 64);
+        cs0 += __shfl_xor(cs0, 32, 64); cs1 += __shfl_xor(cs1, 32, 64); cs2 += __shfl_xor(cs2, 32, 64); cs3 += __shfl_xor(cs3, 32, 64);
+        cq0 += __shfl_xor(cq0, 32, 64); cq1 += __shfl_xor(cq1, 32, 64); cq2 += __shfl_xor(cq2, 32, 64); cq3 += __shfl_xor(cq3, 32, 64);
+        if (lane < 16 && vec_ok) {
+          float* dst = p.col_stats + ((long)(row0 >> 6) * p.N + col) * 2;
+          *(float4*)dst = make_float4(cs0, cq0, cs1, cq1);
+          *(float4*)(dst + 4) = make_float4(cs2, cq2, cs3, cq3);
+        }
       }
     }
-  }
-  // GroupNorm statistics of the tensor just produced (consumed by gn_finalize_cols_kernel): per
-  // 64-row chunk and column, sum and sum of squares of the final fp32 values.  Lanes l, l+16,
-  // l+32, l+48 hold the same 4 columns -> two wavefront shuffles; fixed order, reproducible.
-  if (p.col_stats) {
-    cs0 += __shfl_xor(cs0, 16, 64); cs1 += __shfl_xor(cs1, 16, 64); cs2 += __shfl_xor(cs2, 16, 64); cs3 += __shfl_xor(cs3, 16, 64);
-    cq0 += __shfl_xor(cq0, 16, 64); cq1 += __shfl_xor(cq1, 16, 64); cq2 += __shfl_xor(cq2, 16, 64); cq3 += __shfl_xor(cq3, 16, 64);
-    cs0 += __shfl_xor(cs0, 32, 64); cs1 += __shfl_xor(cs1, 32, 64); cs2 += __shfl_xor(cs2, 32, 64); cs3 += __shfl_xor(cs3, 32, 64);
-    cq0 += __shfl_xor(cq0, 32, 64); cq1 += __shfl_xor(cq1, 32, 64); cq2 += __shfl_xor(cq2, 32, 64); cq3 += __shfl_xor(cq3, 32, 64);
-    if (lane < 16 && vec_ok) {
-      float* dst = p.col_stats + ((long)((m0 + wm * 64) >> 6) * p.N + col) * 2;
-      *(float4*)dst = make_float4(cs0, cq0, cs1, cq1);
-      *(float4*)(dst + 4) = make_float4(cs2, cq2, cs3, cq3);
-    }
-  }
 }
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream -----------
@@ -708,6 +724,8 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
   return T2P_OK;
 }
 
+static int g_dma_geom = 0;   // 0 auto, 1 force 256x128x3, 2 force 128x128x2, 3 force 256x256x2
+static bool g_splitk = true;
 static bool g_use_dma = true;
 static int g_dbg = 0;   // timing-only ablations (results are wrong when non-zero): 1 no epilogue, 2 no DMA in loop, 4 no reads/MFMA
 void set_gemm_dma(bool on) { g_use_dma = on; }
@@ -753,19 +771,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
   }
 }
 
-static bool g_splitk = true;
 void set_gemm_splitk(bool on) { g_splitk = on; }
-static int g_dma_geom = 0;   // 0 auto, 1 force 256x128x3, 2 force 128x128x2
+
 void set_gemm_geom(int v) { g_dma_geom = v; }
+
+static int dma_pick_geom(const GemmParams& p);
+static bool dma_uses_splitk(const GemmParams& p) {
+  const int g = dma_pick_geom(p);
+  const int BM = g == 2 ? 128 : 256, BN = g == 1 ? 256 : 128;
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps;
+  return g_splitk && p.ws && p.nz0 * p.nz1 == 1 && tiles < 192 && nk >= 16;
+}
 
 // true when launch_gemm(p) with p.geglu set will apply the fused GEGLU epilogue
 bool gemm_fuses_geglu(const GemmParams& p) {
   if (!dma_eligible(p) || p.nz0 * p.nz1 != 1 || p.c_f32 || p.R || p.bias_bn || p.bias_m) return false;
   if (p.N % 4 != 0 || p.ldc % 2 != 0) return false;
-  const int BM = (p.M < 256 || g_dma_geom == 2) && g_dma_geom != 1 ? 128 : 256;
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 127) / 128);
-  const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps;
-  return !(g_splitk && tiles < 192 && nk >= 16);
+  return !dma_uses_splitk(p);
 }
 
 // true when launch_gemm(p) will run the LDS-DMA kernel without split-K and with a vector
@@ -773,19 +796,25 @@ bool gemm_fuses_geglu(const GemmParams& p) {
 bool gemm_fuses_col_stats(const GemmParams& p) {
   if (!dma_eligible(p) || p.nz0 * p.nz1 != 1 || !p.c_f32) return false;
   if (p.N % 4 != 0 || p.ldc % 4 != 0 || (p.R && p.ldr % 4 != 0) || (p.bias_bn && p.ld_bn % 4 != 0)) return false;
-  const int BM = (p.M < 256 || g_dma_geom == 2) && g_dma_geom != 1 ? 128 : 256;
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 127) / 128);
-  const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps;
-  if (g_splitk && tiles < 192 && nk >= 16) return false;     // split-K path writes raw partial tiles
+  if (dma_uses_splitk(p)) return false;                      // split-K path writes raw partial tiles
   return p.M % 64 == 0;
 }
 
-template <typename TC, int MODE, int BM, int BN, int NST>
+static int dma_pick_geom(const GemmParams& p) {   // 0: 256x128x3, 1: 256x256x2, 2: 128x128x2
+  if (g_dma_geom == 1) return 0;
+  if (g_dma_geom == 2) return 2;
+  if (g_dma_geom == 3) return 1;
+  if (p.M < 256) return 2;
+  if (p.N >= 256 && p.N % 256 == 0) return 1;     // measured: 860-1020 TFLOP/s vs 710-830 for 256x128 on the conv shapes
+  return 0;
+}
+
+template <typename TC, int MODE, int BM, int BN, int WM, int WN, int NST>
 static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
   constexpr int smem = NST * (BM + BN) * 128;
-  constexpr int threads = (BM / 64) * (BN / 64) * 64;
+  constexpr int threads = WM * WN * 64;
   static bool attr_set = false;
-  auto kern = gemm_dma_kernel<TC, BM, BN, MODE, NST>;
+  auto kern = gemm_dma_kernel<TC, BM, BN, WM, WN, MODE, NST>;
   if (!attr_set) {
     T2P_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
@@ -794,7 +823,7 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
   // split-K when the tile grid cannot fill the chip and the K loop is long (low-resolution levels)
   int nsplit = 1;
   const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps;
-  if (g_splitk && p.ws && p.nz0 * p.nz1 == 1 && tiles_m * tiles_n < 192 && nk >= 16) {
+  if (dma_uses_splitk(p)) {
     nsplit = std::min(std::min(nk / 4, (384 + tiles_m * tiles_n - 1) / (tiles_m * tiles_n)), 32);
     while (nsplit > 1 && (size_t)nsplit * p.M * p.N * 4 > p.ws_bytes) --nsplit;
   }
@@ -823,11 +852,11 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
 
 template <typename TC, int MODE>
 static int launch_dma_mode(const GemmParams& p, hipStream_t stream) {
-  bool small = p.M < 256;             // 128x128 only for short problems (256x128 measured 15-20 % faster otherwise)
-  if (g_dma_geom == 1) small = false;
-  if (g_dma_geom == 2) small = true;
-  if (small) return launch_dma_geom<TC, MODE, 128, 128, 2>(p, stream);
-  return launch_dma_geom<TC, MODE, 256, 128, 3>(p, stream);
+  switch (dma_pick_geom(p)) {
+    case 1: return launch_dma_geom<TC, MODE, 256, 256, 2, 4, 2>(p, stream);
+    case 2: return launch_dma_geom<TC, MODE, 128, 128, 2, 2, 2>(p, stream);
+    default: return launch_dma_geom<TC, MODE, 256, 128, 4, 2, 3>(p, stream);
+  }
 }
 
 template <typename TC>
