@@ -86,13 +86,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal on a one-GPU box: T2P_FORCE_DEVICE=0 T2P_DIST_BACKEND=gloo put every rank on one card
+    dev_index = int(os.environ.get("T2P_FORCE_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+        backend = os.environ.get("T2P_DIST_BACKEND", "nccl")  # "nccl" is RCCL over xGMI on ROCm
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     from text2protein_amd import sampling, sde_lib, synth
     from text2protein_amd._lib import check, load

@@ -805,8 +805,16 @@ static int dma_pick_geom(const GemmParams& p) {   // 0: 256x128x3, 1: 256x256x2,
   if (g_dma_geom == 2) return 2;
   if (g_dma_geom == 3) return 1;
   if (p.M < 256) return 2;
-  if (p.N >= 256 && p.N % 256 == 0) return 1;     // measured: 860-1020 TFLOP/s vs 710-830 for 256x128 on the conv shapes
-  return 0;
+  // largest tile that still gives about one workgroup per CU: big tiles are 15-20 % more efficient
+  // (860-1020 vs 710-830 TFLOP/s on the conv shapes), but a short problem spread over few
+  // workgroups is latency-bound and finishes sooner with more, smaller tiles
+  const long z = (long)p.nz0 * p.nz1;
+  const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * z;
+  const long t128 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * z;
+  if (g_dma_geom == 5) return (p.N >= 256 && p.N % 256 == 0) ? 1 : 0;   // former policy, kept for A/B
+  if (p.N % 256 == 0 && t256 >= 200) return 1;
+  if (t128 >= 200) return 0;
+  return 2;
 }
 
 template <typename TC, int MODE, int BM, int BN, int WM, int WN, int NST>
