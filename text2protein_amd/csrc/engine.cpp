@@ -378,6 +378,12 @@ int Engine::finalize() {
   T2P_TRY(upload_linear("pre_blocks.0.weight", "pre_blocks.0.bias", td, nf_, &pre0_, false, false, DT_F32));
   T2P_TRY(upload_linear("pre_blocks.1.weight", "pre_blocks.1.bias", td, td, &pre1_, false, false, DT_F32));
   T2P_TRY(upload_linear("pre_conv.weight", "pre_conv.bias", nf_, 9 * cfg_.num_channels, &pre_conv_, true, false, DT_F32));
+  {
+    const HostTensor* w = host("pre_conv.weight", {nf_, cfg_.num_channels, 3, 3});
+    if (!w) return T2P_ERR_STATE;
+    std::vector<float> m = to_nk(*w, true, false, 0);      // [nf][tap][C], unpadded
+    T2P_TRY(upload_f32(m, &pre_conv_direct_));
+  }
   std::vector<float> dw((size_t)temb_total_ * td), db(temb_total_);
   auto each_layer = [&](auto&& fn) -> int {
     for (Stage& st : input_stages_) for (Layer& l : st.layers) T2P_TRY(fn(l));
@@ -851,10 +857,12 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
     T2P_HIP_CHECK(hipMemcpyAsync(scale, ones.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
     T2P_HIP_CHECK(hipStreamSynchronize(s));
   }
-  POOL_GET(xin, float*, (size_t)B * HW * cpad_ * 4);
-  T2P_TRY(launch_nchw_to_nhwc(x, xin, B, Cx, HW, cpad_, s));
   POOL_GET(h0, float*, (size_t)B * HW * nf_ * 4);
-  {
+  if ((Cx == 5 || Cx == 8) && pre_conv_direct_) {
+    T2P_TRY(launch_pre_conv(x, pre_conv_direct_, pre_conv_.b, h0, B, Cx, L, L, nf_, s));
+  } else {
+    POOL_GET(xin, float*, (size_t)B * HW * cpad_ * 4);
+    T2P_TRY(launch_nchw_to_nhwc(x, xin, B, Cx, HW, cpad_, s));
     GemmParams p;   // pre_conv always in exact fp32: the input has the dynamic range of sigma_max
     p.dtype = DT_F32; p.a_f32 = 1; p.A0 = xin; p.C0 = cpad_; p.lda0 = cpad_;
     p.taps = 9; p.H = L; p.W = L;
@@ -862,8 +870,8 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
     p.rows_per_batch = HW;
     p.C = h0; p.c_f32 = 1; p.ldc = nf_;
     T2P_TRY(gemm(p, s));
+    pool_.put(xin);
   }
-  pool_.put(xin);
   pool_.put(emb); pool_.put(t1); pool_.put(t2);
 
   std::vector<Act> hs;

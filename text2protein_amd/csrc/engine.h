@@ -130,6 +130,7 @@ class Engine {
   DevLinear pre0_, pre1_, pre_conv_, head_conv_, dense_all_;
   DevNorm head_norm_;
   int temb_total_ = 0;
+  float* pre_conv_direct_ = nullptr;   // [nf][9][C] fp32 weights of the direct input convolution
   float* inv_sigma_ = nullptr;  // [N] fp32, 1 / sigmas[label] (descending sigmas)
   int ctx_B_ = 0, ctx_T_ = 0, ctx_Tpad_ = 0;
   void* splitk_ws_ = nullptr;

@@ -459,6 +459,57 @@ int launch_pool2x2(const float* x, void* out, int dtype, int B, int H, int W, in
   return T2P_OK;
 }
 
+// ================================== input convolution ====================================================
+// pre_conv (reference ncsnpp.py:137,230): 3x3, C = 5 or 8 input channels (NCHW fp32, the sampler
+// state with the dynamic range of sigma_max) -> nf channels NHWC fp32, exact fp32 FMAs.  Too thin
+// for the MFMA GEMM (K = 45): one workgroup takes a 32-pixel row segment, stages the 3 x 34 x C
+// input patch in LDS, and each thread owns one output channel with its 9 C weights in registers;
+// lanes cover consecutive channels, so the NHWC stores are coalesced.
+template <int C>
+__global__ __launch_bounds__(256) void pre_conv_kernel(const float* x, const float* w, const float* bias, float* out, int B,
+                                                       int H, int W, int nf) {
+  constexpr int SEG = 32;
+  __shared__ float patch[C][3][SEG + 2];
+  const int segs = (W + SEG - 1) / SEG;
+  const int seg = blockIdx.x % segs, y = (blockIdx.x / segs) % H, b = blockIdx.x / (segs * H);
+  const int x0 = seg * SEG;
+  for (int i = threadIdx.x; i < C * 3 * (SEG + 2); i += 256) {
+    const int c = i / (3 * (SEG + 2)), r = (i / (SEG + 2)) % 3, col = i % (SEG + 2);
+    const int sy = y + r - 1, sx = x0 + col - 1;
+    patch[c][r][col] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[(((long)b * C + c) * H + sy) * W + sx] : 0.f;
+  }
+  __syncthreads();
+  for (int co = threadIdx.x; co < nf; co += 256) {
+    float wr[C * 9];
+#pragma unroll
+    for (int i = 0; i < C * 9; ++i) wr[i] = w[(long)co * 9 * C + i];       // [co][tap][c]
+    const float bv = bias[co];
+    const int npx = min(SEG, W - x0);
+    for (int px = 0; px < npx; ++px) {
+      float acc = bv;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc = fmaf(patch[c][t / 3][px + t % 3], wr[t * C + c], acc);
+      out[(((long)b * H + y) * W + x0 + px) * nf + co] = acc;
+    }
+  }
+}
+
+int launch_pre_conv(const float* x, const float* w, const float* bias, float* out, int B, int C, int H, int W, int nf,
+                    hipStream_t s) {
+  T2P_REQUIRE(x && w && bias && out && B > 0 && nf > 0, "pre_conv arguments");
+  const int segs = (W + 31) / 32;
+  dim3 grid((unsigned)((long)B * H * segs));
+  switch (C) {
+    case 5: hipLaunchKernelGGL(pre_conv_kernel<5>, grid, dim3(256), 0, s, x, w, bias, out, B, H, W, nf); break;
+    case 8: hipLaunchKernelGGL(pre_conv_kernel<8>, grid, dim3(256), 0, s, x, w, bias, out, B, H, W, nf); break;
+    default: set_last_error("pre_conv: only 5 or 8 input channels have a direct kernel"); return T2P_ERR_INVALID;
+  }
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
 // ================================== NCHW -> padded NHWC ==================================================
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, float* out, int B, int C, int HW, int Cpad) {
   const long total = (long)B * HW;

@@ -51,6 +51,10 @@ int launch_geglu(const float* u, void* out, int dtype, long rows, int inner, hip
 // ---- 2x2 mean pooling of an NHWC fp32 map (skip branch of a down block, layers.py:309-311) ------
 int launch_pool2x2(const float* x, void* out, int dtype, int B, int H, int W, int C, hipStream_t s);
 
+// ---- pre_conv: 3x3, C in {5, 8} NCHW fp32 -> nf NHWC fp32; w = [nf][9][C] fp32 -------------------------
+int launch_pre_conv(const float* x, const float* w, const float* bias, float* out, int B, int C, int H, int W, int nf,
+                    hipStream_t s);
+
 // ---- NCHW fp32 (B,C,L,L) -> NHWC fp32 [B][L*L][Cpad], zero padded channels -----------------------
 int launch_nchw_to_nhwc(const float* x, float* out, int B, int C, int HW, int Cpad, hipStream_t s);
 
