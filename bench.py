@@ -198,9 +198,12 @@ def main():
             # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
             # (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction; profiles/README.md)
             t = json.load(open(tfile[-1]))
-            for k, v in t.items():
-                if k.startswith("gemm_dma_kernel") and ", 1, " in k:
-                    traffic = v["hbm_bytes_per_launch"]
+            best = 0.0
+            for k, v in t.items():      # the conv-mode instantiation that moves the most bytes per step
+                if k.startswith("gemm_dma_kernel") and k.rstrip(">").split(", ")[-2] == "1":
+                    w = v["hbm_bytes_per_launch"] * v.get("launches_fetch", 1)
+                    if w > best:
+                        best, traffic = w, v["hbm_bytes_per_launch"]
         out["roofline"] = {
             "bound": "mfma", "kernel": kname,
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
