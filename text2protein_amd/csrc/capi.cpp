@@ -317,6 +317,7 @@ int t2p_debug_set(int key, int value) {
   else if (key == 5) g_flash_attention = value != 0;
   else if (key == 6) g_fuse_gn_stats = value != 0;
   else if (key == 7) g_fuse_geglu = value != 0;
+  else if (key == 8) set_gemm_ring(value);
   else return T2P_ERR_INVALID;
   return T2P_OK;
 }

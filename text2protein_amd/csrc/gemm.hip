@@ -306,16 +306,21 @@ template <int I> __device__ inline void lds_read_b128(u32x4_t& dst, unsigned add
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(I * 4096));
 }
 
-template <typename TC, int BM, int BN, int WM, int WN, int MODE, int NST>
+template <typename TC, int BM, int BN, int WM, int WN, int MODE, int NST, int NSTB = NST>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams p, const int tiles_m, const int tiles_n, const int dbg) {
+  // NST stages for the A (activation) tile, NSTB for the B (weight) tile.  NSTB < NST gives the
+  // activations -- which come from L2 / Infinity Cache -- a longer lead than the L2-hot weights
+  // within the 160 KiB of LDS (256 x 256: 3 x 32 KiB + 2 x 32 KiB).
   constexpr int BK = 64;
   constexpr int NW = WM * WN;
   constexpr int TI = BM / WM / 32, TJ = BN / WN / 32;  // 32x32 MFMA tiles per wave
   static_assert(NW == 8 || NW == 4, "4 or 8 wavefronts");
   static_assert((TI == 2 || TI == 4) && (TJ == 2 || TJ == 4) && TI * TJ <= 8, "wave tile");
-  static_assert(NW * 16384 <= NST * (BM + BN) * 128, "epilogue staging must fit the ring");
+  static_assert(NW * 16384 <= NST * BM * 128 + NSTB * BN * 128, "epilogue staging must fit the ring");
+  static_assert(NSTB == NST || NSTB == NST - 1, "B ring is as deep as the A ring or one stage shallower");
   constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;  // DMA instructions per wave per K-tile (8 rows each)
-  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int ASTAGE = BM * 128, BSTAGE = BN * 128;
+  constexpr int BRING = NST * ASTAGE;                            // byte offset of the B ring
   constexpr int TAPS = MODE == 0 ? 1 : 9;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -410,7 +415,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   }
 
   auto issue = [&](int kl, int part) {   // part 0: A rows, 1: B rows, 2: both; kl counts from this block's first K-tile
-    unsigned char* st = smem + (kl % NST) * STAGE;
+    unsigned char* sta = smem + (kl % NST) * ASTAGE;
+    unsigned char* stb = smem + BRING + (kl % NSTB) * BSTAGE;
     const int kt = kt_lo + kl;
     const int chunk = kt / TAPS;
     const int tap = kt - chunk * TAPS;
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
       } else {
         voff = (second ? a_off1[j] : a_off0[j]) + udelta;
       }
-      unsigned char* dst = st + (wave * A_INSTR + j) * 1024;
+      unsigned char* dst = sta + (wave * A_INSTR + j) * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, T2P_LDS_PTR(dst), 16, ok ? voff : DMA_OOB, 0, 0, 0);
     }
     const unsigned kb = (unsigned)(((long)tap * Ctot + c0) * 2);
@@ -442,7 +448,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j) {
       const unsigned voff = b_off[j] + kb;   // rows beyond N carry DMA_OOB: adding kb (< 2 GiB) keeps them out of range
-      unsigned char* dst = st + BM * 128 + (wave * B_INSTR + j) * 1024;
+      unsigned char* dst = stb + (wave * B_INSTR + j) * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, T2P_LDS_PTR(dst), 16, voff, 0, 0, 0);
     }
   };
@@ -464,31 +470,40 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       a_fo[s] = (unsigned)(ra * 128 + (((2 * s + lh) ^ ((ra >> 1) & 7)) << 4));
-      b_fo[s] = (unsigned)(BM * 128 + rb * 128 + (((2 * s + lh) ^ ((rb >> 1) & 7)) << 4));
+      b_fo[s] = (unsigned)(BRING + rb * 128 + (((2 * s + lh) ^ ((rb >> 1) & 7)) << 4));
     }
   }
 
   const unsigned lds_base = (unsigned)(unsigned long long)T2P_LDS_PTR(smem);
-  constexpr int AHEAD = NST - 1;                       // K-tiles in flight beyond the one being multiplied
+  // Issue order per iteration kt: B(kt + AB) first, then A(kt + AA).  vmcnt counts in order, so at
+  // the top of iteration kt everything up to and including A(kt) and B(kt) has landed when at most
+  // the loads issued after them are outstanding.
+  constexpr int AA = NST - 1, AB = NSTB - 1;            // lead (K-tiles) of the A and B streams
   issue(0, 2);
-  if (AHEAD > 1 && nk > 1) issue(1, 2);
+  if (AA > 1 && nk > 1) issue(1, AB > 1 ? 2 : 0);
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed when at most (AHEAD - 1) later tiles' loads are still outstanding
-    if (AHEAD > 1 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + B_INSTR) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // outstanding after A(kt), B(kt) in issue order: symmetric ring: the (AA - 1) younger tiles;
+    // asymmetric (AB == AA - 1): only A(kt + 1 .. kt + AA - 1)
+    if (kt + 1 < nk && AA > 1) {
+      if (NSTB == NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AA - 1) * (A_INSTR + B_INSTR)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AA - 1) * A_INSTR) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
-    const bool more = kt + AHEAD < nk && !(dbg & 2);
-    if (dbg & 4) { if (more) issue(kt + AHEAD, 2); continue; }
+    const bool more_a = kt + AA < nk && !(dbg & 2), more_b = kt + AB < nk && !(dbg & 2);
+    if (dbg & 4) { if (more_b) issue(kt + AB, 1); if (more_a) issue(kt + AA, 0); continue; }
     // Fragment reads go through inline asm: hipcc would otherwise put `s_waitcnt vmcnt(0)` in
     // front of every ds_read that may alias an in-flight LDS-DMA write and drain the ring.  The
     // reads of k-step s+1 are in flight while the MFMAs of step s run (lgkmcnt counts LDS ops in
     // order: <= TI + TJ outstanding means step s has landed).
-    const unsigned st_off = lds_base + (unsigned)((kt % NST) * STAGE);
+    const unsigned sa_off = lds_base + (unsigned)((kt % NST) * ASTAGE);
+    const unsigned sb_off = lds_base + (unsigned)((kt % NSTB) * BSTAGE);
     u32x4_t fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
 #define T2P_RD(S, FA, FB)                                                                          \
   {                                                                                                \
-    const unsigned aa = st_off + a_fo[S];                                                          \
-    const unsigned ba = st_off + b_fo[S];                                                          \
+    const unsigned aa = sa_off + a_fo[S];                                                          \
+    const unsigned ba = sb_off + b_fo[S];                                                          \
     lds_read_b128<0>(FA[0], aa);                                                                   \
     lds_read_b128<0>(FB[0], ba);                                                                   \
     lds_read_b128<1>(FA[1], aa);                                                                   \
@@ -516,11 +531,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
     T2P_RD(1, fa1, fb1)
     T2P_WAIT(NRD, fa0, fb0)
     T2P_MMA(fa0, fb0)
-    if (more) issue(kt + AHEAD, 0);
+    if (more_b) issue(kt + AB, 1);
     T2P_RD(2, fa0, fb0)
     T2P_WAIT(NRD, fa1, fb1)
     T2P_MMA(fa1, fb1)
-    if (more) issue(kt + AHEAD, 1);
+    if (more_a) issue(kt + AA, 0);
     T2P_RD(3, fa1, fb1)
     T2P_WAIT(NRD, fa0, fb0)
     T2P_MMA(fa0, fb0)
@@ -724,6 +739,8 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
   return T2P_OK;
 }
 
+static int g_dma_ring = 1;   // 256x256 ring: 1 = 2 + 2 stages (A/B, default); 0 = 3 A + 2 B stages (160 KiB; measured equal)
+void set_gemm_ring(int v) { g_dma_ring = v; }
 static int g_dma_geom = 0;   // 0 auto, 1 force 256x128x3, 2 force 128x128x2, 3 force 256x256x2
 static bool g_splitk = true;
 static bool g_use_dma = true;
@@ -817,12 +834,12 @@ static int dma_pick_geom(const GemmParams& p) {   // 0: 256x128x3, 1: 256x256x2,
   return 2;
 }
 
-template <typename TC, int MODE, int BM, int BN, int WM, int WN, int NST>
+template <typename TC, int MODE, int BM, int BN, int WM, int WN, int NST, int NSTB = NST>
 static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
-  constexpr int smem = NST * (BM + BN) * 128;
+  constexpr int smem = NST * BM * 128 + NSTB * BN * 128;
   constexpr int threads = WM * WN * 64;
   static bool attr_set = false;
-  auto kern = gemm_dma_kernel<TC, BM, BN, WM, WN, MODE, NST>;
+  auto kern = gemm_dma_kernel<TC, BM, BN, WM, WN, MODE, NST, NSTB>;
   if (!attr_set) {
     T2P_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
@@ -861,7 +878,9 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
 template <typename TC, int MODE>
 static int launch_dma_mode(const GemmParams& p, hipStream_t stream) {
   switch (dma_pick_geom(p)) {
-    case 1: return launch_dma_geom<TC, MODE, 256, 256, 2, 4, 2>(p, stream);
+    case 1:
+      if (g_dma_ring == 1) return launch_dma_geom<TC, MODE, 256, 256, 2, 4, 2>(p, stream);
+      return launch_dma_geom<TC, MODE, 256, 256, 2, 4, 3, 2>(p, stream);   // 3 A stages + 2 B stages = 160 KiB
     case 2: return launch_dma_geom<TC, MODE, 128, 128, 2, 2, 2>(p, stream);
     default: return launch_dma_geom<TC, MODE, 256, 128, 4, 2, 3>(p, stream);
   }

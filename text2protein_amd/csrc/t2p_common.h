@@ -128,6 +128,7 @@ bool gemm_fuses_geglu(const GemmParams& p);
 void set_gemm_dma(bool on);
 void set_gemm_debug(int v);
 void set_gemm_geom(int v);
+void set_gemm_ring(int v);
 void set_gemm_splitk(bool on);
 extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible
 extern bool g_fuse_geglu;      // engine: GEGLU gating inside the ff1 GEMM epilogue

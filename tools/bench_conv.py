@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--taps", type=int, default=9)
     ap.add_argument("--dbg", type=int, default=0)
     ap.add_argument("--geom", type=int, default=0)
+    ap.add_argument("--ring", type=int, default=0)
     ap.add_argument("--no-dma", action="store_true")
     a = ap.parse_args()
     from text2protein_amd import _lib
@@ -31,6 +32,7 @@ def main():
     dt = _lib.DTYPE_NAMES[a.dtype]
     lib.t2p_debug_set(1, a.dbg)
     lib.t2p_debug_set(2, a.geom)
+    lib.t2p_debug_set(8, a.ring)
     lib.t2p_debug_set(0, 0 if a.no_dma else 1)
     td = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[dt]
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -59,7 +61,7 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
     fl = 2.0 * a.B * a.H * a.W * a.cout * a.taps * a.cin
-    print(f"{a.dtype} B{a.B} {a.H}x{a.W} cin{a.cin} cout{a.cout} taps{a.taps} dbg{a.dbg} geom{a.geom}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s", flush=True)
+    print(f"{a.dtype} B{a.B} {a.H}x{a.W} cin{a.cin} cout{a.cout} taps{a.taps} dbg{a.dbg} geom{a.geom} ring{a.ring}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":
