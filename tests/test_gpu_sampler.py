@@ -88,3 +88,29 @@ def test_registry_behaviour():
         sampling.get_corrector("no_such_corrector")
     assert sampling.get_predictor("reverse_diffusion") is sampling.ReverseDiffusionPredictor
     assert sampling.get_corrector("langevin") is sampling.LangevinCorrector
+
+
+def test_two_corrector_steps_match_oracle():
+    """sampling.n_steps_each = 2 (no shipped config uses it): HIP fused and class routes against the oracle on
+    identical fp32 noise (the reference would draw float64 noise for the second inner step)."""
+    from oracle import t2p_oracle as O
+    from text2protein_amd import synth, sde_lib, sampling
+    from text2protein_amd.model import HipScoreModel
+    cfg = cfg_tiny()
+    cfg.device = "cuda"
+    cfg.sampling.n_steps_each = 2
+    sd = synth.synth_state_dict(cfg, 1)
+    B, C_, L = 2, cfg.data.num_channels, cfg.data.max_res_num
+    ctx = synth.synth_context(B, 3, cfg.model.context_dim, 1)
+    g = torch.Generator().manual_seed(7)
+    draws = [torch.randn(B, C_, L, L, generator=g) for _ in range(1 + 3 * cfg.model.num_scales)]
+    it = iter(draws)
+    want, nfe = O.pc_sampler_ve(sd, cfg, (B, C_, L, L), ctx, noise_fn=lambda s: next(it))
+    model = HipScoreModel(cfg, dtype="f32")
+    model.load_state_dict(sd)
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=cfg.model.num_scales)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, C_, L, L), 1e-5, force_classes=True)
+    it = iter(draws)
+    got, nfe2 = fn(model, context=ctx, noise_fn=lambda s: next(it))
+    assert nfe == nfe2 == cfg.model.num_scales * 3
+    assert rel_l2(got.cpu(), want) < 1e-5
