@@ -71,6 +71,12 @@ int t2p_engine_set_context(t2p_engine* e, const float* context, int batch, int t
 /* x: device fp32 (batch, C, L, L); labels: device int32 [batch] time labels (index into the
  * descending sigma table); out: device fp32 (batch, C, L, L) = network output / sigma[label]. */
 int t2p_engine_score(t2p_engine* e, const float* x, const int32_t* labels, float* out, int batch, void* stream);
+/* as t2p_engine_score, with optional fractional time values for the sinusoidal embedding: the VP
+ * branch of get_score_fn passes labels = t * (N - 1) as floats (models/utils.py:150-152); the
+ * model embeds the float and indexes its sigma table with the truncated value (ncsnpp.py:223-224).
+ * labels_f: device fp32 [batch] or NULL (= embed the integer labels). */
+int t2p_engine_score_ex(t2p_engine* e, const float* x, const int32_t* labels, const float* labels_f, float* out,
+                        int batch, void* stream);
 /* bytes of device memory currently held (weights + cached activations) */
 int64_t t2p_engine_device_bytes(const t2p_engine* e);
 

@@ -308,6 +308,55 @@ def pc_sampler_ve(P, config, shape, context, condition=None, eps=1e-5, noise_fn=
         return (x_mean if s.noise_removal else x), N * (s.n_steps_each + 1)
 
 
+def pc_sampler_vp(P, config, shape, context, condition=None, eps=1e-3, noise_fn=None, trace=None, n_steps_limit=None):
+    """pc_sampler (sampling.py:245-289) for the VP SDE: DDPM discretisation (sde_lib.py:148-157),
+    VP branch of get_score_fn (models/utils.py:138-157: labels = t * (N - 1) as floats,
+    score = -model / sqrt(1 - alphas_cumprod)[labels.long()]) and the Langevin alpha lookup
+    (sampling.py:184-186).  No shipped config selects it; kept as the lowest-priority row of the path."""
+    m, s = config.model, config.sampling
+    N = m.num_scales
+    noise_fn = noise_fn or (lambda shp: torch.randn(*shp))
+    vp = vp_tables(m.beta_min, m.beta_max, N)
+
+    def score_fn(x, t):
+        labels = t * (N - 1)
+        out = unet_forward(P, config, x, labels, context)
+        std = vp["sqrt_1m_alphas_cumprod"][labels.long()]
+        return -out / std[:, None, None, None]
+
+    with torch.no_grad():
+        x = noise_fn(shape)                                   # VPSDE.prior_sampling, sde_lib.py:139-140
+        ts = timesteps(N, eps)
+        x, cmask = apply_conditions(x, condition)
+        x_initial = x.detach().clone()
+        x_mean = x
+        for i in range(N if n_steps_limit is None else n_steps_limit):
+            vec_t = torch.ones(shape[0]) * ts[i]
+            k = (vec_t * (N - 1)).long()
+            alpha = vp["alphas"][k]
+            for _ in range(s.n_steps_each):
+                grad = score_fn(x, vec_t)
+                noise = noise_fn(tuple(x.shape))
+                B = x.shape[0]
+                grad_norm = torch.norm(grad.reshape(B, -1), dim=-1).mean()
+                noise_norm = torch.norm(noise.reshape(B, -1), dim=-1).mean()
+                step = (s.snr * noise_norm / grad_norm) ** 2 * 2 * alpha
+                x_mean = x + step[:, None, None, None] * grad
+                x = x_mean + torch.sqrt(step * 2)[:, None, None, None] * noise
+            x = torch.where(cmask, x, x_initial).float()
+            score = score_fn(x, vec_t)
+            z = noise_fn(tuple(x.shape))
+            beta = vp["discrete_betas"][k]
+            f = torch.sqrt(alpha)[:, None, None, None] * x - x
+            G = torch.sqrt(beta)
+            x, x_mean = reverse_diffusion_update(x, score, z, G, s.probability_flow, f=f)
+            x = torch.where(cmask, x, x_initial).float()
+            if trace is not None:
+                trace.append((x.clone(), x_mean.clone()))
+        x_mean = torch.where(cmask, x_mean, x_initial).float()
+        return (x_mean if s.noise_removal else x), N * (s.n_steps_each + 1)
+
+
 # --------------------------------------------------------------------------------------------
 # condition builders (pure-tensor parts of reference utils.py)
 # --------------------------------------------------------------------------------------------

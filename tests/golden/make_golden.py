@@ -127,6 +127,33 @@ def sampler_fixture(name, cfg, seed, B, T, cond_kind):
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
 
 
+def sampler_fixture_vp(name, cfg, seed, B, T):
+    """5-step VP run of the reference (training.sde == vpsde, eps = 1e-3 as in sampling_6d.py:80-82)."""
+    model, sd = build_reference_model(cfg, seed)
+    C, L = cfg.data.num_channels, cfg.data.max_res_num
+    N = cfg.model.num_scales
+    shape = (B, C, L, L)
+    ctx = synth.synth_context(B, T, cfg.model.context_dim, seed)
+    sde = sde_lib.VPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=N)
+    fn = sampling.get_sampling_fn(cfg, sde, shape, 1e-3)
+    torch.manual_seed(4321 + seed)
+    ref, nfe = fn(model, condition={}, context=ctx)
+    draws = []
+
+    def noise_fn(shp):
+        z = torch.randn(*shp)
+        draws.append(z)
+        return z
+
+    torch.manual_seed(4321 + seed)
+    got, _ = O.pc_sampler_vp(sd, cfg, shape, ctx, noise_fn=noise_fn)
+    err = float((got - ref).norm() / ref.norm())
+    print(f"[{name}] oracle vs reference VP sample rel-L2 = {err:.3e}, nfe={nfe}")
+    assert err < 1e-5
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), context=ctx.numpy(), sample=ref.numpy(), nfe=np.int64(nfe),
+                        seed=np.int64(seed), noise=torch.stack(draws).numpy())
+
+
 def tables_fixture():
     """discrete_sigmas, G_i, labels for N in {100, 1000, 2000} from the reference VESDE and
     get_score_fn (sde_lib.py:199-245, models/utils.py:159-171), plus the model sigmas buffer."""
@@ -176,6 +203,8 @@ def main():
     forward_fixture("tinyB_forward", cfg_b, seed=3, B=2, T=5)
     for kind in ("none", "length", "length+inpainting"):
         sampler_fixture("tiny_sampler_" + kind.replace("+", "_"), cfg, seed=0, B=2, T=3, cond_kind=kind)
+    # VP needs beta_max / N < 1 (alpha = 1 - beta > 0): 40 steps instead of the 5 of the VE fixtures
+    sampler_fixture_vp("tiny_sampler_vp", tiny_config(**{"model.num_scales": 40, "training.sde": "vpsde"}), seed=0, B=2, T=3)
     tables_fixture()
 
 

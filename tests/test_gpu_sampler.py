@@ -114,3 +114,25 @@ def test_two_corrector_steps_match_oracle():
     got, nfe2 = fn(model, context=ctx, noise_fn=lambda s: next(it))
     assert nfe == nfe2 == cfg.model.num_scales * 3
     assert rel_l2(got.cpu(), want) < 1e-5
+
+
+def test_vp_sde_route_matches_reference_run():
+    """VP SDE through the predictor / corrector classes (fractional time labels in the engine) against the
+    reference's own 40-step VP run."""
+    from text2protein_amd import synth, sde_lib, sampling
+    from text2protein_amd.config import tiny_config
+    from text2protein_amd.model import HipScoreModel
+    g = load_golden("tiny_sampler_vp")
+    cfg = tiny_config(**{"model.num_scales": 40, "training.sde": "vpsde"})
+    cfg.device = "cuda"
+    model = HipScoreModel(cfg, dtype="f32")
+    model.load_state_dict(synth.synth_state_dict(cfg, int(g["seed"])))
+    sde = sde_lib.VPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=cfg.model.num_scales)
+    fn = sampling.get_sampling_fn(cfg, sde, (2, 5, 16, 16), 1e-3)
+    it = iter([torch.from_numpy(z) for z in g["noise"]])
+    out, nfe = fn(model, condition={}, context=torch.from_numpy(g["context"]), noise_fn=lambda shp: next(it))
+    torch.cuda.synchronize()
+    assert nfe == int(g["nfe"])
+    err = rel_l2(out.cpu(), g["sample"])
+    print(f"VP route: final sample rel-L2 vs reference = {err:.3e}")
+    assert err < 1e-4

@@ -97,3 +97,14 @@ def test_condition_builders():
     rows = torch.zeros(8, dtype=torch.bool)
     rows[[1, 2, 3, 6]] = True
     assert torch.equal(s[0], rows[:, None] | rows[None, :])
+
+
+def test_vp_sampler_matches_reference():
+    """Lowest-priority row of the path: VP SDE, 40 steps (VP needs beta_max / N < 1)."""
+    g = load_golden("tiny_sampler_vp")
+    cfg = tiny_config(**{"model.num_scales": 40, "training.sde": "vpsde"})
+    P = synth.synth_state_dict(cfg, int(g["seed"]))
+    it = iter([torch.from_numpy(z) for z in g["noise"]])
+    out, nfe = O.pc_sampler_vp(P, cfg, (2, 5, 16, 16), torch.from_numpy(g["context"]), noise_fn=lambda shp: next(it))
+    assert nfe == int(g["nfe"]) == 80
+    assert rel_l2(out, g["sample"]) < TOL

@@ -50,6 +50,7 @@ SIGNATURES = {
     "t2p_engine_finalize": (_i, [_vp]),
     "t2p_engine_set_context": (_i, [_vp, _vp, _i, _i, _vp]),
     "t2p_engine_score": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "t2p_engine_score_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "t2p_engine_device_bytes": (_i64, [_vp]),
     "t2p_sampler_create": (_i, [_vp, C.POINTER(SamplerConfig), _vp, C.POINTER(_vp)]),
     "t2p_sampler_destroy": (None, [_vp]),

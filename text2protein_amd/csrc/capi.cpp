@@ -90,6 +90,14 @@ int t2p_engine_score(t2p_engine* e, const float* x, const int32_t* labels, float
   API_END
 }
 
+int t2p_engine_score_ex(t2p_engine* e, const float* x, const int32_t* labels, const float* labels_f, float* out, int batch,
+                        void* stream) {
+  API_BEGIN
+  T2P_REQUIRE(e && labels, "null argument");
+  return e->impl.score(x, labels, nullptr, out, batch, (hipStream_t)stream, labels_f);
+  API_END
+}
+
 int64_t t2p_engine_device_bytes(const t2p_engine* e) { return e ? e->impl.device_bytes() : 0; }
 
 int t2p_sampler_create(t2p_engine* e, const t2p_sampler_config* cfg, const float* g_table, t2p_sampler** out) {

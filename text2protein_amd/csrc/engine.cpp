@@ -834,7 +834,8 @@ int Engine::set_context(const float* ctx, int B, int T, hipStream_t s) {
 }
 
 // UNetModel.forward (ncsnpp.py:220-263)
-int Engine::score(const float* x, const int* labels, const int* step_counter, float* out, int B, hipStream_t s) {
+int Engine::score(const float* x, const int* labels, const int* step_counter, float* out, int B, hipStream_t s,
+                  const float* labels_f) {
   T2P_REQUIRE(finalized_, "finalize the engine first");
   T2P_REQUIRE(x && out && B > 0 && (labels || step_counter), "score arguments");
   const int L = cfg_.max_res_num, HW = L * L, Cx = cfg_.num_channels, N = cfg_.num_scales;
@@ -843,7 +844,8 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
   POOL_GET(t1, float*, (size_t)R * temb_dim_ * 4);
   POOL_GET(t2, float*, (size_t)R * temb_dim_ * 4);
   POOL_GET(tb, float*, (size_t)R * temb_total_ * 4);
-  T2P_TRY(launch_timestep_embedding(labels, step_counter, emb, R, nf_, s));
+  T2P_REQUIRE(!labels_f || labels, "fractional labels come with integer labels (sigma index)");
+  T2P_TRY(launch_timestep_embedding(labels, labels_f, step_counter, emb, R, nf_, s));
   T2P_TRY(launch_small_linear(emb, (const float*)pre0_.w, pre0_.b, t1, R, nf_, temb_dim_, 0, s));
   T2P_TRY(launch_small_linear(t1, (const float*)pre1_.w, pre1_.b, t2, R, temb_dim_, temb_dim_, 0, s));
   T2P_TRY(launch_small_linear(t2, (const float*)dense_all_.w, dense_all_.b, tb, R, temb_dim_, temb_total_, 1, s));

@@ -87,7 +87,8 @@ class Engine {
   int finalize();
   int set_context(const float* ctx, int B, int T, hipStream_t s);
   // labels == nullptr: every row uses *step_counter (device int)
-  int score(const float* x, const int* labels, const int* step_counter, float* out, int B, hipStream_t s);
+  int score(const float* x, const int* labels, const int* step_counter, float* out, int B, hipStream_t s,
+            const float* labels_f = nullptr);
   int64_t device_bytes() const { return (int64_t)pool_.held_bytes(); }
   const t2p_model_config& cfg() const { return cfg_; }
   DevPool& pool() { return pool_; }

@@ -528,12 +528,13 @@ int launch_nchw_to_nhwc(const float* x, float* out, int B, int C, int HW, int Cp
 }
 
 // ================================== time embedding ========================================================
-__global__ void timestep_embedding_kernel(const int* labels, const int* step_counter, float* emb, int rows, int dim) {
+__global__ void timestep_embedding_kernel(const int* labels, const float* labels_f, const int* step_counter, float* emb,
+                                          int rows, int dim) {
   const int half = dim / 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * dim) return;
   const int r = i / dim, k = i - r * dim;
-  const float t = (float)(labels ? labels[r] : *step_counter);
+  const float t = labels_f ? labels_f[r] : (float)(labels ? labels[r] : *step_counter);
   // reference: emb = log(10000) / (half - 1) as a python float, then exp(arange * -emb) in fp32
   const float e = (float)(9.210340371976184 / (double)(half - 1));
   float val = 0.f;
@@ -546,10 +547,12 @@ __global__ void timestep_embedding_kernel(const int* labels, const int* step_cou
   emb[i] = val;
 }
 
-int launch_timestep_embedding(const int* labels, const int* step_counter, float* emb, int rows, int dim, hipStream_t s) {
-  T2P_REQUIRE((labels || step_counter) && emb && dim >= 4, "timestep embedding arguments");
+int launch_timestep_embedding(const int* labels, const float* labels_f, const int* step_counter, float* emb, int rows, int dim,
+                              hipStream_t s) {
+  T2P_REQUIRE((labels || labels_f || step_counter) && emb && dim >= 4, "timestep embedding arguments");
   const int tot = rows * dim;
-  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, labels, step_counter, emb, rows, dim);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, labels, labels_f, step_counter, emb, rows,
+                     dim);
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }

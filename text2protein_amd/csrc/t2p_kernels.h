@@ -62,8 +62,10 @@ int launch_nchw_to_nhwc(const float* x, float* out, int B, int C, int HW, int Cp
 // emb[r][:] = [sin(t f_k) | cos(t f_k)] (layers.py:97-111); label of row r = labels ? labels[r]
 // : *step_counter (device scalar) -- the sampler advances a device-side counter so that a
 // captured graph of one PC step can be replayed.
-int launch_timestep_embedding(const int* labels, const int* step_counter, float* emb, int rows, int dim,
-                              hipStream_t s);
+// labels_f (optional): fractional time values for the embedding (VP path: labels = t * (N - 1),
+// reference models/utils.py:150-152); the sigma lookup always uses the integer labels
+int launch_timestep_embedding(const int* labels, const float* labels_f, const int* step_counter, float* emb, int rows,
+                              int dim, hipStream_t s);
 // out[r][n] = bias[n] + sum_k act(in[r][k]) * W[n][k]   (fp32; act = SiLU when silu != 0)
 int launch_small_linear(const float* in, const float* W, const float* bias, float* out, int rows, int K, int N,
                         int silu, hipStream_t s);

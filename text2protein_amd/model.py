@@ -158,9 +158,12 @@ class HipScoreModel:
         elif self._ctx_key is None:
             raise T2PError("context is required (context_dim differs from the block width, SURVEY 8(a))")
         x = x.to(self.device, torch.float32).contiguous()
-        labels = labels.to(self.device).to(torch.int32).contiguous()
+        labels = labels.to(self.device)
+        # float labels (VP branch): embed the float, index sigmas with .long() like ncsnpp.py:223-224
+        labels_f = labels.to(torch.float32).contiguous() if labels.is_floating_point() else None
+        labels_i = labels.long().to(torch.int32).contiguous()
         out = torch.empty_like(x)
-        check(self.lib.t2p_engine_score(self._h, ptr(x), ptr(labels), ptr(out), x.shape[0], stream_ptr()))
+        check(self.lib.t2p_engine_score_ex(self._h, ptr(x), ptr(labels_i), ptr(labels_f), ptr(out), x.shape[0], stream_ptr()))
         return out
 
     forward = __call__
