@@ -795,7 +795,7 @@ void set_gemm_geom(int v) { g_dma_geom = v; }
 static int dma_pick_geom(const GemmParams& p);
 static bool dma_uses_splitk(const GemmParams& p) {
   const int g = dma_pick_geom(p);
-  const int BM = g == 2 ? 128 : 256, BN = g == 1 ? 256 : 128;
+  const int BM = g == 2 ? 128 : (g == 3 ? 512 : 256), BN = g == 1 ? 256 : 128;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps;
   return g_splitk && p.ws && p.nz0 * p.nz1 == 1 && tiles < 192 && nk >= 16;
@@ -817,7 +817,7 @@ bool gemm_fuses_col_stats(const GemmParams& p) {
   return p.M % 64 == 0;
 }
 
-static int dma_pick_geom(const GemmParams& p) {   // 0: 256x128x3, 1: 256x256x2, 2: 128x128x2
+static int dma_pick_geom(const GemmParams& p) {   // 0: 256x128x3, 1: 256x256x2, 2: 128x128x2, 3: 512x128x2
   if (g_dma_geom == 1) return 0;
   if (g_dma_geom == 2) return 2;
   if (g_dma_geom == 3) return 1;
@@ -830,6 +830,8 @@ static int dma_pick_geom(const GemmParams& p) {   // 0: 256x128x3, 1: 256x256x2,
   const long t128 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * z;
   if (g_dma_geom == 5) return (p.N >= 256 && p.N % 256 == 0) ? 1 : 0;   // former policy, kept for A/B
   if (p.N % 256 == 0 && t256 >= 200) return 1;
+  const long t512 = (long)((p.M + 511) / 512) * ((p.N + 127) / 128) * z;
+  if (g_dma_geom != 6 && p.N <= 128 && t512 >= 200) return 3;            // narrow outputs: tall tile, same 128x64 wave tile
   if (t128 >= 200) return 0;
   return 2;
 }
@@ -882,6 +884,7 @@ static int launch_dma_mode(const GemmParams& p, hipStream_t stream) {
       if (g_dma_ring == 1) return launch_dma_geom<TC, MODE, 256, 256, 2, 4, 2>(p, stream);
       return launch_dma_geom<TC, MODE, 256, 256, 2, 4, 3, 2>(p, stream);   // 3 A stages + 2 B stages = 160 KiB
     case 2: return launch_dma_geom<TC, MODE, 128, 128, 2, 2, 2>(p, stream);
+    case 3: return launch_dma_geom<TC, MODE, 512, 128, 4, 2, 2>(p, stream);
     default: return launch_dma_geom<TC, MODE, 256, 128, 4, 2, 3>(p, stream);
   }
 }
