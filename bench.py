@@ -111,7 +111,7 @@ def main():
 
     if args.gemm_geom:
         check(load().t2p_debug_set(2, args.gemm_geom))
-    for key, env in ((3, "T2P_SPLITK"), (4, "T2P_RAW_COPIES"), (5, "T2P_FLASH"), (6, "T2P_FUSE_GN"), (7, "T2P_FUSE_GEGLU"), (8, "T2P_GEMM_RING")):      # development A/B switches
+    for key, env in ((3, "T2P_SPLITK"), (4, "T2P_RAW_COPIES"), (5, "T2P_FLASH"), (6, "T2P_FUSE_GN"), (7, "T2P_FUSE_GEGLU"), (8, "T2P_GEMM_RING"), (9, "T2P_LOWP_H1")):      # development A/B switches
         if env in os.environ:
             check(load().t2p_debug_set(key, int(os.environ[env])))
     t_setup = time.perf_counter()

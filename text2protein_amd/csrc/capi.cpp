@@ -326,6 +326,7 @@ int t2p_debug_set(int key, int value) {
   else if (key == 6) g_fuse_gn_stats = value != 0;
   else if (key == 7) g_fuse_geglu = value != 0;
   else if (key == 8) set_gemm_ring(value);
+  else if (key == 9) g_lowp_h1 = value != 0;
   else return T2P_ERR_INVALID;
   return T2P_OK;
 }

@@ -13,6 +13,7 @@ namespace t2p {
 
 bool g_fuse_gn_stats = true;
 bool g_fuse_geglu = true;
+bool g_lowp_h1 = true;
 bool g_raw_copies = true;
 bool g_flash_attention = true;
 static thread_local std::string g_last_error;
@@ -493,7 +494,7 @@ int Engine::gemm(GemmParams& p, hipStream_t s) {
 int Engine::gemm_stats(GemmParams& p, float** cstats, hipStream_t s) {
   *cstats = nullptr;
   T2P_TRY(attach_ws(p));          // the fuse predicate depends on the split-K decision
-  if (g_fuse_gn_stats && gemm_fuses_col_stats(p)) {
+  if (g_fuse_gn_stats && (gemm_fuses_col_stats(p) || gemm_fuses_col_stats_lowp(p))) {
     *cstats = (float*)pool_.get((size_t)(p.M / 64) * p.N * 2 * 4);
     if (!*cstats) return T2P_ERR_HIP;
     p.col_stats = *cstats;
@@ -538,6 +539,8 @@ int Engine::group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps,
   GroupNormApplyArgs g;
   g.x0 = a.x0; g.x1 = a.x1; g.C0 = a.C0; g.C1 = a.C1; g.B = B; g.H = x.H; g.W = x.W; g.G = n.G;
   g.stats = stats; g.gamma = n.gamma; g.beta = n.beta; g.silu = silu; g.down = down; g.dtype = dtype();
+  g.x0_lowp = x.lowp;
+  T2P_REQUIRE(!x.lowp || (x.cstats && !x1), "a 16-bit activation needs fused statistics and a single source");
   const size_t opix = (size_t)B * (down ? x.H / 2 : x.H) * (down ? x.W / 2 : x.W);
   POOL_GET(o, void*, opix * C * dtype_size(dtype()));
   g.out = o;
@@ -568,6 +571,7 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
   const bool want_raw = g_raw_copies && L.has_conv2 && !L.down && dt != DT_F32;
   T2P_TRY(group_norm(x, skip, L.gn0, 1e-6f, 1, L.down, B, &a0, s, want_raw ? &xraw : nullptr));
   float* h1_stats = nullptr;
+  bool h1_lowp = false;
   POOL_GET(h1, float*, (size_t)rows_out * Cout * 4);
   {
     GemmParams p;
@@ -576,10 +580,19 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     p.Bw = L.conv0.w; p.ldb = L.conv0.K; p.M = (int)rows_out; p.N = Cout;
     p.bias_n = L.conv0.b; p.bias_bn = tb_ + L.temb_off; p.ld_bn = tb_ld_; p.rows_per_batch = Ho * Wo;
     p.C = h1; p.c_f32 = 1; p.ldc = Cout;
+    // h1 is read once more, by GroupNorm_1 only: when its statistics come out of this epilogue
+    // (computed from the fp32 values) the tensor itself is stored in the compute dtype
+    T2P_TRY(attach_ws(p));
+    if (g_lowp_h1 && dt != DT_F32 && g_fuse_gn_stats && gemm_fuses_col_stats(p) && (Ho * Wo) % 64 == 0) {
+      p.c_f32 = 0;
+      h1_lowp = gemm_fuses_col_stats_lowp(p);
+      if (!h1_lowp) p.c_f32 = 1;
+    }
     T2P_TRY(gemm_stats(p, &h1_stats, s));
+    if (h1_lowp && !h1_stats) return T2P_ERR_STATE;
   }
   pool_.put(a0);
-  Act h1a{h1, Cout, Ho, Wo, h1_stats};
+  Act h1a{h1, Cout, Ho, Wo, h1_stats, h1_lowp};
   void* a1 = nullptr;
   T2P_TRY(group_norm(h1a, nullptr, L.gn1, 1e-6f, 1, 0, B, &a1, s));
   free_act(h1a);

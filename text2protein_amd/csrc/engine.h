@@ -75,6 +75,7 @@ struct Act {  // an NHWC fp32 activation
   float* p = nullptr;
   int C = 0, H = 0, W = 0;
   float* cstats = nullptr;   // optional per-64-row column sums of p (GemmParams::col_stats), for the consumer's GroupNorm
+  bool lowp = false;         // p holds compute-dtype (16-bit) values instead of fp32 (block-internal tensors only)
 };
 
 class Engine {

@@ -810,6 +810,13 @@ bool gemm_fuses_geglu(const GemmParams& p) {
 
 // true when launch_gemm(p) will run the LDS-DMA kernel without split-K and with a vector
 // epilogue, i.e. when a non-null p.col_stats will be filled
+// same with a compute-dtype (16-bit) output: statistics are still taken from the fp32 values
+bool gemm_fuses_col_stats_lowp(const GemmParams& p) {
+  GemmParams q = p;
+  q.c_f32 = 1;
+  return !p.c_f32 && p.dtype != DT_F32 && gemm_fuses_col_stats(q);
+}
+
 bool gemm_fuses_col_stats(const GemmParams& p) {
   if (!dma_eligible(p) || p.nz0 * p.nz1 != 1 || !p.c_f32) return false;
   if (p.N % 4 != 0 || p.ldc % 4 != 0 || (p.R && p.ldr % 4 != 0) || (p.bias_bn && p.ld_bn % 4 != 0)) return false;

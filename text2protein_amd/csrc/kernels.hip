@@ -179,12 +179,25 @@ int launch_gn_stats(const GroupNormArgs& a, hipStream_t s) {
 // ================================== GroupNorm apply (+SiLU, +2x2 mean) ==========================
 __device__ inline float silu_fast(float x) { return x * __frcp_rn(1.f + __expf(-x)); }
 
+template <typename T> __device__ inline float4 load4(const T* p);
+template <> __device__ inline float4 load4<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ inline float4 load4<bf16_t>(const bf16_t* p) {
+  const uint2 u = *(const uint2*)p;
+  return make_float4(bf16_bits_to_f32((uint16_t)u.x), bf16_bits_to_f32((uint16_t)(u.x >> 16)),
+                     bf16_bits_to_f32((uint16_t)u.y), bf16_bits_to_f32((uint16_t)(u.y >> 16)));
+}
+template <> __device__ inline float4 load4<f16_t>(const f16_t* p) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const h4 v = *(const h4*)p;
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+
 // grid (pixel chunks, B, ceil(C / 1024)).  A thread keeps one 4-channel vector: its scale/shift
 // (rstd*gamma, beta - mean*rstd*gamma) are computed once, then it walks output pixels with 32-bit
 // indexing; consecutive lanes cover consecutive channels (coalesced 16-byte loads, 8/16-byte stores).
 static constexpr int GNA_PIX_PER_BLOCK = 64;
 
-template <typename TO>
+template <typename TO, typename TI>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormApplyArgs a) {
   const int C = a.C0 + a.C1;
   const int Ho = a.down ? a.H >> 1 : a.H, Wo = a.down ? a.W >> 1 : a.W;
@@ -197,8 +210,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormApplyArgs a) {
   const int v = tid % nvec, po = tid / nvec;
   const int c = c_lo + v * 4;
   const int cpg = C / a.G;
-  const float* src; int ld, cc;
-  if (c < a.C0) { src = a.x0; ld = a.C0; cc = c; } else { src = a.x1; ld = a.C1; cc = c - a.C0; }
+  const TI* src; int ld, cc;
+  if (c < a.C0) { src = (const TI*)a.x0; ld = a.C0; cc = c; } else { src = (const TI*)a.x1; ld = a.C1; cc = c - a.C0; }
   src += (long)b * a.H * a.W * ld + cc;
   const float4 ga = *(const float4*)(a.gamma + c), be = *(const float4*)(a.beta + c);
   float sc[4], sh[4];
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormApplyArgs a) {
   if (!a.down) {
 #pragma unroll 2
     for (int p = p_lo + po; p < p_hi; p += ppi) {
-      const float4 t = *(const float4*)(src + (long)p * ld);
+      const float4 t = load4<TI>(src + (long)p * ld);
       if (raw) store4<TO>(raw + (long)p * C, t.x, t.y, t.z, t.w);
       float y0 = t.x * sc[0] + sh[0], y1 = t.y * sc[1] + sh[1], y2 = t.z * sc[2] + sh[2], y3 = t.w * sc[3] + sh[3];
       if (a.silu) { y0 = silu_fast(y0); y1 = silu_fast(y1); y2 = silu_fast(y2); y3 = silu_fast(y3); }
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormApplyArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int ip = (2 * oy + (q >> 1)) * a.W + 2 * ox + (q & 1);
-        const float4 t = *(const float4*)(src + (long)ip * ld);
+        const float4 t = load4<TI>(src + (long)ip * ld);
         float y0 = t.x * sc[0] + sh[0], y1 = t.y * sc[1] + sh[1], y2 = t.z * sc[2] + sh[2], y3 = t.w * sc[3] + sh[3];
         if (a.silu) { y0 = silu_fast(y0); y1 = silu_fast(y1); y2 = silu_fast(y2); y3 = silu_fast(y3); }
         o0 += y0; o1 += y1; o2 += y2; o3 += y3;
@@ -251,10 +264,17 @@ int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s) {
   T2P_REQUIRE(!(a.down && a.raw_out), "raw copy is not produced together with down-sampling");
   const int HWo = (a.down ? a.H / 2 : a.H) * (a.down ? a.W / 2 : a.W);
   dim3 grid((HWo + GNA_PIX_PER_BLOCK - 1) / GNA_PIX_PER_BLOCK, a.B, (C + 1023) / 1024);
+  T2P_REQUIRE(!a.x0_lowp || (a.C1 == 0 && a.dtype != DT_F32), "16-bit GroupNorm input: single source, 16-bit dtype");
   switch (a.dtype) {
-    case DT_F32: hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, a); break;
-    case DT_BF16: hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, a); break;
-    case DT_F16: hipLaunchKernelGGL(gn_apply_kernel<f16_t>, grid, dim3(256), 0, s, a); break;
+    case DT_F32: hipLaunchKernelGGL((gn_apply_kernel<float, float>), grid, dim3(256), 0, s, a); break;
+    case DT_BF16:
+      if (a.x0_lowp) hipLaunchKernelGGL((gn_apply_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gn_apply_kernel<bf16_t, float>), grid, dim3(256), 0, s, a);
+      break;
+    case DT_F16:
+      if (a.x0_lowp) hipLaunchKernelGGL((gn_apply_kernel<f16_t, f16_t>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gn_apply_kernel<f16_t, float>), grid, dim3(256), 0, s, a);
+      break;
     default: set_last_error("gn_apply: bad dtype"); return T2P_ERR_INVALID;
   }
   T2P_HIP_CHECK(hipGetLastError());

@@ -125,12 +125,14 @@ struct GemmParams {
 int launch_gemm(const GemmParams& p, hipStream_t stream);
 bool gemm_fuses_col_stats(const GemmParams& p);
 bool gemm_fuses_geglu(const GemmParams& p);
+bool gemm_fuses_col_stats_lowp(const GemmParams& p);
 void set_gemm_dma(bool on);
 void set_gemm_debug(int v);
 void set_gemm_geom(int v);
 void set_gemm_ring(int v);
 void set_gemm_splitk(bool on);
 extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible
+extern bool g_lowp_h1;         // engine: block-internal conv0 output stored in the compute dtype
 extern bool g_fuse_geglu;      // engine: GEGLU gating inside the ff1 GEMM epilogue
 extern bool g_fuse_gn_stats;   // engine: GroupNorm statistics from the producing GEMM epilogue
 extern bool g_raw_copies;   // engine: feed 1x1 shortcut / proj_out GEMMs with compute-dtype copies

@@ -32,6 +32,7 @@ struct GroupNormApplyArgs {
   int down = 0;                        // 2x2 mean of the activated map (layers.py:185-188)
   void* out = nullptr;                 // [B][H'*W'][C] in `dtype`
   int dtype = DT_F32;
+  int x0_lowp = 0;                     // x0 is stored in `dtype` (16-bit) instead of fp32 (single source only)
   void* raw_out = nullptr;             // optional: un-normalised x (concat of both sources) in `dtype`,
                                        // same resolution as the input (not with `down`)
 };
