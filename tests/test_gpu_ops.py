@@ -246,3 +246,39 @@ def test_philox_normal_moments(lib):
     check(lib, lib.t2p_op_philox_normal(P(out3), n, 1234, 1, None))
     torch.cuda.synchronize()
     assert torch.equal(out, out3)                                     # counter-based: reproducible
+
+
+@pytest.mark.parametrize("geom,ring", [(1, 1), (2, 1), (3, 1), (3, 0), (3, 2), (0, 1), (0, 2)])
+def test_dma_kernel_variants_agree(lib, geom, ring):
+    """Every LDS-DMA geometry (256x128x3, 128x128x2, 256x256 with 2+2 / 3+2 rings and with the 16x16x32
+    MFMA shape) forced on the same operands: conv with halo + up-sampling, ragged M / N GEMM."""
+    try:
+        check(lib, lib.t2p_debug_set(2, geom))
+        check(lib, lib.t2p_debug_set(8, ring))
+        g = torch.Generator().manual_seed(geom * 10 + ring)
+        for dt in (1, 2):
+            td = TDT[dt]
+            for (B, H, W, Cin, Cout, up) in [(2, 24, 20, 128, 256, 0), (1, 32, 32, 64, 512, 1), (3, 16, 16, 192, 256, 0)]:
+                hs, ws = (H // 2, W // 2) if up else (H, W)
+                x = torch.randn(B, Cin, hs, ws, generator=g).to(td)
+                w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(td)
+                b = torch.randn(Cout, generator=g)
+                xin = x.repeat_interleave(2, 2).repeat_interleave(2, 3) if up else x
+                ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+                out = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+                check(lib, lib.t2p_op_conv3x3(dt, P(dev(x.permute(0, 2, 3, 1))), 0, P(dev(w.permute(0, 2, 3, 1))), P(dev(b)), P(out),
+                                              B, H, W, Cin, Cout, up, None))
+                torch.cuda.synchronize()
+                assert rel_l2(out.cpu(), ref) < 3e-6, (geom, ring, dt, B, H, W, Cin, Cout, up)
+            for (M, N, K) in [(1000, 256, 192), (700, 520, 64), (4096, 512, 1024)]:
+                a = torch.randn(M, K, generator=g).to(td)
+                w = (torch.randn(N, K, generator=g) / K ** 0.5).to(td)
+                res = torch.randn(M, N, generator=g)
+                ref = (a.double() @ w.double().T + res.double()) * 0.5
+                out = torch.full((M, N), float("nan"), device="cuda")
+                check(lib, lib.t2p_op_gemm(dt, P(dev(a)), 0, P(dev(w)), P(out), 1, M, N, K, K, K, N, None, P(dev(res)), 0.5, None))
+                torch.cuda.synchronize()
+                assert rel_l2(out.cpu(), ref) < 3e-6, (geom, ring, dt, M, N, K)
+    finally:
+        lib.t2p_debug_set(2, 0)
+        lib.t2p_debug_set(8, 2)

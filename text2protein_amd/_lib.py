@@ -105,6 +105,11 @@ def load(build_if_missing: bool = True):
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # development switches: T2P_DEBUG="key=value,key=value" -> t2p_debug_set (include/t2p.h)
+    for kv in filter(None, os.environ.get("T2P_DEBUG", "").split(",")):
+        k, v = kv.split("=")
+        if lib.t2p_debug_set(int(k), int(v)) != 0:
+            raise T2PError(f"bad T2P_DEBUG entry {kv}")
     return lib
 
 

@@ -306,7 +306,25 @@ template <int I> __device__ inline void lds_read_b128(u32x4_t& dst, unsigned add
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(I * 4096));
 }
 
-template <typename TC, int BM, int BN, int WM, int WN, int MODE, int NST, int NSTB = NST>
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <typename TC> struct Mma16;
+template <> struct Mma16<bf16_t> {
+  __device__ static inline void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma16<f16_t> {
+  __device__ static inline void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <int I> __device__ inline void lds_read_b128_2k(u32x4_t& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(I * 2048));
+}
+
+// MF16: use v_mfma_f32_16x16x32 (sustains a higher clock than 32x32x16 at equal cycles per FLOP in
+// LDS-fed loops, MI355X_MICROARCH.md "DVFS give-back" item 7) -- 128 x 64 wave tiles only.
+template <typename TC, int BM, int BN, int WM, int WN, int MODE, int NST, int NSTB = NST, bool MF16 = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams p, const int tiles_m, const int tiles_n, const int dbg) {
   // NST stages for the A (activation) tile, NSTB for the B (weight) tile.  NSTB < NST gives the
   // activations -- which come from L2 / Infinity Cache -- a longer lead than the L2-hot weights
@@ -318,6 +336,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   static_assert((TI == 2 || TI == 4) && (TJ == 2 || TJ == 4) && TI * TJ <= 8, "wave tile");
   static_assert(NW * 16384 <= NST * BM * 128 + NSTB * BN * 128, "epilogue staging must fit the ring");
   static_assert(NSTB == NST || NSTB == NST - 1, "B ring is as deep as the A ring or one stage shallower");
+  static_assert(!MF16 || (TI == 4 && TJ == 2), "the 16x16x32 variant is written for 128 x 64 wave tiles");
   constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;  // DMA instructions per wave per K-tile (8 rows each)
   constexpr int ASTAGE = BM * 128, BSTAGE = BN * 128;
   constexpr int BRING = NST * ASTAGE;                            // byte offset of the B ring
@@ -441,25 +460,33 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
         voff = (second ? a_off1[j] : a_off0[j]) + udelta;
       }
       unsigned char* dst = sta + (wave * A_INSTR + j) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, T2P_LDS_PTR(dst), 16, ok ? voff : DMA_OOB, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, T2P_LDS_PTR(dst), 16, (ok && !(dbg & 64)) ? voff : DMA_OOB, 0, 0, 0);
     }
     const unsigned kb = (unsigned)(((long)tap * Ctot + c0) * 2);
     if (part != 0)
 #pragma unroll
     for (int j = 0; j < B_INSTR; ++j) {
-      const unsigned voff = b_off[j] + kb;   // rows beyond N carry DMA_OOB: adding kb (< 2 GiB) keeps them out of range
+      const unsigned voff = (dbg & 64) ? DMA_OOB : b_off[j] + kb;   // rows beyond N carry DMA_OOB: adding kb (< 2 GiB) keeps them out of range
       unsigned char* dst = stb + (wave * B_INSTR + j) * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, T2P_LDS_PTR(dst), 16, voff, 0, 0, 0);
     }
   };
 
-  f32x16 acc[TI][TJ];
+  f32x16 acc[MF16 ? 1 : TI][MF16 ? 1 : TJ];
+  f32x4_t acc16[MF16 ? 8 : 1][MF16 ? 4 : 1];      // 16x16 tiles: row tile i (16 rows), column tile j (16 columns)
+  if constexpr (MF16) {
 #pragma unroll
-  for (int i = 0; i < TI; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < TJ; ++j)
+      for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  } else {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+  }
 
   // fragment read offsets: row (wave row base + i*32 + lr), chunk (2 s + lh) ^ ((row >> 1) & 7)
   // (the i-th 32-row tile of a wave is i * 4096 bytes further and has the same swizzle term,
@@ -471,6 +498,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
     for (int s = 0; s < 4; ++s) {
       a_fo[s] = (unsigned)(ra * 128 + (((2 * s + lh) ^ ((ra >> 1) & 7)) << 4));
       b_fo[s] = (unsigned)(BRING + rb * 128 + (((2 * s + lh) ^ ((rb >> 1) & 7)) << 4));
+    }
+  }
+
+  // 16x16x32: lane (r = lane & 15, g = lane >> 4) reads 16 bytes of row (tile base + r) at logical
+  // chunk 4 ks + g of the 128-byte K-slice; tile i is i * 16 rows = i * 2048 bytes further (same
+  // swizzle term), reached through the immediate offset
+  unsigned a16[2], b16[2];
+  {
+    const int r = lane & 15, g = lane >> 4;
+    const int ra = wm * (BM / WM) + r, rb = wn * (BN / WN) + r;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      a16[ks] = (unsigned)(ra * 128 + (((4 * ks + g) ^ ((ra >> 1) & 7)) << 4));
+      b16[ks] = (unsigned)(BRING + rb * 128 + (((4 * ks + g) ^ ((rb >> 1) & 7)) << 4));
     }
   }
 
@@ -499,6 +540,40 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
     // order: <= TI + TJ outstanding means step s has landed).
     const unsigned sa_off = lds_base + (unsigned)((kt % NST) * ASTAGE);
     const unsigned sb_off = lds_base + (unsigned)((kt % NSTB) * BSTAGE);
+    if constexpr (MF16) {
+      // fragments: B of k-step 0 / 1 (4 column tiles each), A low / high half (4 row tiles each)
+      u32x4_t B0[4], B1[4], AL[4], AH[4];
+#define T2P_RD4(F, ADDR, I0)                                                                        \
+  lds_read_b128_2k<I0>(F[0], ADDR); lds_read_b128_2k<I0 + 1>(F[1], ADDR);                            \
+  lds_read_b128_2k<I0 + 2>(F[2], ADDR); lds_read_b128_2k<I0 + 3>(F[3], ADDR);
+#define T2P_W8(N, X, Y)                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(Y[0]), "+v"(Y[1]), \
+               "+v"(Y[2]), "+v"(Y[3]) : "n"(N));
+#define T2P_M16(A, B, I0)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)       \
+      Mma16<TC>::run(A[i], B[j], acc16[I0 + i][j]);
+      const unsigned aa0 = sa_off + a16[0], aa1 = sa_off + a16[1], bb0 = sb_off + b16[0], bb1 = sb_off + b16[1];
+      T2P_RD4(B0, bb0, 0)
+      T2P_RD4(AL, aa0, 0)
+      T2P_RD4(AH, aa0, 4)
+      T2P_W8(4, B0, AL)
+      T2P_M16(AL, B0, 0)
+      if (more_b) issue(kt + AB, 1);
+      T2P_RD4(AL, aa1, 0)
+      T2P_W8(4, B0, AH)
+      T2P_M16(AH, B0, 4)
+      if (more_a) issue(kt + AA, 0);
+      T2P_RD4(B1, bb1, 0)
+      T2P_RD4(AH, aa1, 4)
+      T2P_W8(4, B1, AL)
+      T2P_M16(AL, B1, 0)
+      T2P_W8(0, B1, AH)
+      T2P_M16(AH, B1, 4)
+#undef T2P_RD4
+#undef T2P_W8
+#undef T2P_M16
+      continue;
+    }
     u32x4_t fa0[TI], fb0[TJ], fa1[TI], fb1[TJ];
 #define T2P_RD(S, FA, FB)                                                                          \
   {                                                                                                \
@@ -551,7 +626,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   // 16 KiB slice of the now idle LDS ring, 64 rows at a time, and read back row-contiguous, so
   // that bias / residual loads and the output stores are 16-byte vectors covering whole 256-byte
   // row segments (per-lane dword stores are store-issue bound: 64 instructions per wave, not 16).
-  if ((dbg & 1) && acc[0][0][0] != 123.456f) return;
+  if ((dbg & 1) && (MF16 ? acc16[0][0][0] : acc[0][0][0]) != 123.456f) return;
   __builtin_amdgcn_s_barrier();                       // every wave is done reading the last stage
   float* stg = (float*)(smem + wave * 16384);         // [64 rows][64 cols] fp32
   const long coff = (long)z0 * p.sC_z0 + (long)z1 * p.sC_z1;
@@ -568,13 +643,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
 #pragma unroll
     for (int hj = 0; hj < TJ / 2; ++hj) {             // 64-column slabs
       if (hi + hj > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // previous slab fully read back
+      if constexpr (MF16) {
+        // 16x16 accumulator: column = lane & 15, row = (lane >> 4) * 4 + register
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int v = 0; v < 16; ++v)
-            stg[(i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 64 + j * 32 + lr] = acc[2 * hi + i][2 * hj + j][v];
+            for (int v = 0; v < 4; ++v)
+              stg[(i * 16 + (lane >> 4) * 4 + v) * 64 + j * 16 + (lane & 15)] = acc16[4 * hi + i][4 * hj + j][v];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+              stg[(i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 64 + j * 32 + lr] = acc[2 * hi + i][2 * hj + j][v];
+      }
       // same-wave LDS write -> read: the compiler orders them (lgkmcnt); no barrier needed
       const int row0 = m0 + wm * (BM / WM) + hi * 64;
       const int col = n0 + wn * (BN / WN) + hj * 64 + cq;
@@ -739,7 +825,10 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
   return T2P_OK;
 }
 
-static int g_dma_ring = 1;   // 256x256 ring: 1 = 2 + 2 stages (A/B, default); 0 = 3 A + 2 B stages (160 KiB; measured equal)
+// 128 x 64 wave-tile geometries: 2 = 2 + 2 ring stages with v_mfma_16x16x32 (default: +5 % over the
+// 32x32x16 shape, it sustains a higher clock); 1 = 2 + 2 stages, 32x32x16; 0 = 3 A + 2 B stages
+// (160 KiB; measured equal to 1)
+static int g_dma_ring = 2;
 void set_gemm_ring(int v) { g_dma_ring = v; }
 static int g_dma_geom = 0;   // 0 auto, 1 force 256x128x3, 2 force 128x128x2, 3 force 256x256x2
 static bool g_splitk = true;
@@ -843,12 +932,12 @@ static int dma_pick_geom(const GemmParams& p) {   // 0: 256x128x3, 1: 256x256x2,
   return 2;
 }
 
-template <typename TC, int MODE, int BM, int BN, int WM, int WN, int NST, int NSTB = NST>
+template <typename TC, int MODE, int BM, int BN, int WM, int WN, int NST, int NSTB = NST, bool MF16 = false>
 static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
   constexpr int smem = NST * BM * 128 + NSTB * BN * 128;
   constexpr int threads = WM * WN * 64;
   static bool attr_set = false;
-  auto kern = gemm_dma_kernel<TC, BM, BN, WM, WN, MODE, NST, NSTB>;
+  auto kern = gemm_dma_kernel<TC, BM, BN, WM, WN, MODE, NST, NSTB, MF16>;
   if (!attr_set) {
     T2P_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
@@ -888,10 +977,13 @@ template <typename TC, int MODE>
 static int launch_dma_mode(const GemmParams& p, hipStream_t stream) {
   switch (dma_pick_geom(p)) {
     case 1:
+      if (g_dma_ring == 2) return launch_dma_geom<TC, MODE, 256, 256, 2, 4, 2, 2, true>(p, stream);   // 16x16x32 MFMA
       if (g_dma_ring == 1) return launch_dma_geom<TC, MODE, 256, 256, 2, 4, 2>(p, stream);
       return launch_dma_geom<TC, MODE, 256, 256, 2, 4, 3, 2>(p, stream);   // 3 A stages + 2 B stages = 160 KiB
     case 2: return launch_dma_geom<TC, MODE, 128, 128, 2, 2, 2>(p, stream);
-    case 3: return launch_dma_geom<TC, MODE, 512, 128, 4, 2, 2>(p, stream);
+    case 3:
+      if (g_dma_ring == 2) return launch_dma_geom<TC, MODE, 512, 128, 4, 2, 2, 2, true>(p, stream);
+      return launch_dma_geom<TC, MODE, 512, 128, 4, 2, 2>(p, stream);
     default: return launch_dma_geom<TC, MODE, 256, 128, 4, 2, 3>(p, stream);
   }
 }
