@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="chains per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("T2P_GRAPH", "0")),
+                    help="replay each PC step from a captured hipGraph instead of launching its kernels one by one")
     ap.add_argument("--gemm-geom", type=int, default=int(os.environ.get("T2P_GEMM_GEOM", "0")),
                     help="development: 0 auto, 1 force 256x128x3, 2 force 128x128x2 LDS-DMA GEMM geometry")
     return ap.parse_args()
@@ -140,13 +142,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    side = torch.cuda.Stream(device=dev) if args.graph else None      # stream capture needs a real stream
+    run_step = stepper.step
+    if args.graph:
+        def run_step(a, b):
+            with torch.cuda.stream(side):
+                stepper.step_graph(a, b)
+        torch.cuda.synchronize()
+        for _ in range(2):                                            # eager step + capture
+            run_step(x, x_mean)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
-        stepper.step(x, x_mean)
+        run_step(x, x_mean)
     gathered = [torch.empty_like(x_mean) for _ in range(world)] if dist is not None else None
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        stepper.step(x, x_mean)
+        run_step(x, x_mean)
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
     if dist is not None:
         dist.all_gather(gathered, x_mean)                    # the single collective of a run
     barrier()

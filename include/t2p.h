@@ -114,6 +114,11 @@ int t2p_sampler_reset(t2p_sampler* s, int step, void* stream);
  * (parity runs); NULL = generate on device. */
 int t2p_sampler_step(t2p_sampler* s, float* x, float* x_mean, const float* noise_corrector,
                      const float* noise_predictor, void* stream);
+/* The same step replayed from a captured hipGraph (on-device noise only).  The first call runs
+ * eagerly (it sizes the activation pool), the second captures, later calls replay; x / x_mean /
+ * the condition pointers must stay the same between calls (a change triggers a re-capture).
+ * `stream` must be a real stream (capture on the NULL stream is not allowed). */
+int t2p_sampler_step_graph(t2p_sampler* s, float* x, float* x_mean, void* stream);
 /* Full run: x must hold the (already conditioned) prior sample on entry when `prior_given`, else it
  * is drawn on device (randn * sigma_max, then mask applied).  out receives x_mean (denoise) or x. */
 int t2p_sampler_run(t2p_sampler* s, float* x, float* out, int prior_given, int n_steps, void* stream);

@@ -139,6 +139,13 @@ int t2p_sampler_step(t2p_sampler* s, float* x, float* x_mean, const float* noise
   API_END
 }
 
+int t2p_sampler_step_graph(t2p_sampler* s, float* x, float* x_mean, void* stream) {
+  API_BEGIN
+  T2P_REQUIRE(s, "null sampler");
+  return s->impl.step_graph(x, x_mean, (hipStream_t)stream);
+  API_END
+}
+
 int t2p_sampler_run(t2p_sampler* s, float* x, float* out, int prior_given, int n_steps, void* stream) {
   API_BEGIN
   T2P_REQUIRE(s, "null sampler");

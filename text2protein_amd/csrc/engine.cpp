@@ -1006,6 +1006,35 @@ int Sampler::step(float* x, float* x_mean, const float* nc, const float* np, hip
   return T2P_OK;
 }
 
+Sampler::~Sampler() {
+  if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+}
+
+int Sampler::step_graph(float* x, float* x_mean, hipStream_t s) {
+  T2P_REQUIRE(x && x_mean, "step_graph needs explicit x and x_mean buffers");
+  if (eager_steps_ < 1) {            // one eager step first: fills the activation pool (no hipMalloc under capture)
+    ++eager_steps_;
+    return step(x, x_mean, nullptr, nullptr, s);
+  }
+  if (graph_exec_ && (graph_x_ != x || graph_xm_ != x_mean || graph_mask_ != mask_)) {
+    (void)hipGraphExecDestroy(graph_exec_);
+    graph_exec_ = nullptr;
+  }
+  if (!graph_exec_) {
+    hipGraph_t graph = nullptr;
+    T2P_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = step(x, x_mean, nullptr, nullptr, s);
+    const hipError_t ec = hipStreamEndCapture(s, &graph);
+    if (rc != T2P_OK) return rc;
+    T2P_HIP_CHECK(ec);
+    T2P_HIP_CHECK(hipGraphInstantiate(&graph_exec_, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    graph_x_ = x; graph_xm_ = x_mean; graph_mask_ = mask_;
+  }
+  T2P_HIP_CHECK(hipGraphLaunch(graph_exec_, s));
+  return T2P_OK;
+}
+
 int Sampler::run(float* x, float* out, int prior_given, int n_steps, hipStream_t s) {
   T2P_REQUIRE(x && out, "null pointer");
   if (n_steps <= 0 || n_steps > cfg_.N) n_steps = cfg_.N;

@@ -149,7 +149,11 @@ class Sampler {
   int set_condition(const uint8_t* mask, const float* x_initial) { mask_ = mask; x_init_ = x_initial; return T2P_OK; }
   int reset(int step, hipStream_t s);
   int step(float* x, float* x_mean, const float* nc, const float* np, hipStream_t s);
+  // step() through a captured hipGraph (device noise only): first call with a given (x, x_mean,
+  // condition) captures, later calls replay.  The step reads its index from the device counter.
+  int step_graph(float* x, float* x_mean, hipStream_t s);
   int run(float* x, float* out, int prior_given, int n_steps, hipStream_t s);
+  ~Sampler();
 
  private:
   Engine* e_;
@@ -164,6 +168,11 @@ class Sampler {
   float* sums_ = nullptr;
   float* xmean_ = nullptr;
   long n_ = 0, per_sample_ = 0;
+  hipGraphExec_t graph_exec_ = nullptr;
+  float* graph_x_ = nullptr;
+  float* graph_xm_ = nullptr;
+  const uint8_t* graph_mask_ = nullptr;
+  int eager_steps_ = 0;
 };
 
 }  // namespace t2p

@@ -277,6 +277,10 @@ class PCStepper:
         check(self.lib.t2p_sampler_step(self._h, ptr(x), ptr(x_mean), ptr(noise_corrector), ptr(noise_predictor),
                                         stream_ptr()))
 
+    def step_graph(self, x, x_mean):
+        """One PC step replayed from a captured hipGraph (device noise; needs a non-default stream)."""
+        check(self.lib.t2p_sampler_step_graph(self._h, ptr(x), ptr(x_mean), stream_ptr()))
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):
