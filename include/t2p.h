@@ -166,7 +166,8 @@ int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int
  * out6 = {conv3x3: ms, flops, launches, other GEMMs: ms, flops, launches} since t2p_profile_begin */
 int t2p_profile_begin(void);
 /* development switches: key 0 = enable (1) / disable (0) the LDS-DMA GEMM kernel; key 1 = timing-only
- * ablation mask of that kernel (non-zero values produce wrong results; never set in product code) */
+ * ablation mask of that kernel (bits 1..64 produce wrong results; bits 128 / 256 only switch off the
+ * staggered DMA issue order of the two wave halves, results unchanged; never set in product code) */
 int t2p_debug_set(int key, int value);
 int t2p_profile_end(double* out6);
 

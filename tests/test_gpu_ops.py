@@ -282,3 +282,31 @@ def test_dma_kernel_variants_agree(lib, geom, ring):
     finally:
         lib.t2p_debug_set(2, 0)
         lib.t2p_debug_set(8, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom,ring", [(3, 2), (3, 1), (1, 0), (6, 2)])
+def test_dma_issue_order_does_not_change_results(lib, geom, ring):
+    """The staggered DMA issue order of the two wave halves (default) against the same kernel with the
+    stagger switched off (debug bits 128 / 256): only the instruction order differs, so bit-identical."""
+    try:
+        check(lib, lib.t2p_debug_set(2, geom))
+        check(lib, lib.t2p_debug_set(8, ring))
+        g = torch.Generator().manual_seed(77)
+        B, H, W, Cin, Cout = 2, 40, 36, 256, 256
+        x = dev(torch.randn(B, H, W, Cin, generator=g).half())
+        w = dev((torch.randn(Cout, 9 * Cin, generator=g) / (9 * Cin) ** 0.5).half())
+        b = dev(torch.randn(Cout, generator=g))
+        outs = []
+        for mask in (0, 128, 256):
+            check(lib, lib.t2p_debug_set(1, mask))
+            out = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+            check(lib, lib.t2p_op_conv3x3(2, P(x), 0, P(w), P(b), P(out), B, H, W, Cin, Cout, 0, None))
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+        assert torch.isfinite(outs[0]).all()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    finally:
+        lib.t2p_debug_set(1, 0)
+        lib.t2p_debug_set(2, 0)
+        lib.t2p_debug_set(8, 2)

@@ -318,6 +318,7 @@ template <> struct Mma16<f16_t> {
     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
 };
+__device__ inline bool g_stagger_dbg(int dbg) { return (dbg & 128) == 0; }   // debug bit 128 turns the stagger off
 template <int I> __device__ inline void lds_read_b128_2k(u32x4_t& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(I * 2048));
 }
@@ -553,20 +554,31 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)       \
       Mma16<TC>::run(A[i], B[j], acc16[I0 + i][j]);
       const unsigned aa0 = sa_off + a16[0], aa1 = sa_off + a16[1], bb0 = sb_off + b16[0], bb1 = sb_off + b16[1];
+      // Waves w and w+4 share a SIMD.  The second half of the workgroup issues all of its DMA before
+      // its matrix work, the first half in between: the two waves of a SIMD then run different
+      // phases (one in the matrix pipe while the other issues DMA / waits on LDS), not in lockstep.
+      const bool early = g_stagger_dbg(dbg) && wave >= (WM * WN) / 2;
+      const bool late = g_stagger_dbg(dbg) && !(dbg & 256) && !early;
+      if (early) {
+        if (more_b) issue(kt + AB, 1);
+        if (more_a) issue(kt + AA, 0);
+      }
       T2P_RD4(B0, bb0, 0)
       T2P_RD4(AL, aa0, 0)
       T2P_RD4(AH, aa0, 4)
       T2P_W8(4, B0, AL)
       T2P_M16(AL, B0, 0)
-      if (more_b) issue(kt + AB, 1);
+      if (!early && !late && more_b) issue(kt + AB, 1);
       T2P_RD4(AL, aa1, 0)
       T2P_W8(4, B0, AH)
       T2P_M16(AH, B0, 4)
-      if (more_a) issue(kt + AA, 0);
+      if (!early && !late && more_a) issue(kt + AA, 0);
+      if (late && more_b) issue(kt + AB, 1);
       T2P_RD4(B1, bb1, 0)
       T2P_RD4(AH, aa1, 4)
       T2P_W8(4, B1, AL)
       T2P_M16(AL, B1, 0)
+      if (late && more_a) issue(kt + AA, 0);
       T2P_W8(0, B1, AH)
       T2P_M16(AH, B1, 4)
 #undef T2P_RD4
@@ -602,15 +614,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
     // VALU + buffer_load...lds) is issued between MFMA groups so that it overlaps the matrix
     // pipe instead of holding every wave of the workgroup in a VALU-only phase.
     constexpr int NRD = TI + TJ;
+    const bool early = WM * WN == 8 && g_stagger_dbg(dbg) && wave >= 4;   // see the 16x16x32 loop above
+    if (early) {
+      if (more_b) issue(kt + AB, 1);
+      if (more_a) issue(kt + AA, 0);
+    }
     T2P_RD(0, fa0, fb0)
     T2P_RD(1, fa1, fb1)
     T2P_WAIT(NRD, fa0, fb0)
     T2P_MMA(fa0, fb0)
-    if (more_b) issue(kt + AB, 1);
+    if (!early && more_b) issue(kt + AB, 1);
     T2P_RD(2, fa0, fb0)
     T2P_WAIT(NRD, fa1, fb1)
     T2P_MMA(fa1, fb1)
-    if (more_a) issue(kt + AA, 0);
+    if (!early && more_a) issue(kt + AA, 0);
     T2P_RD(3, fa1, fb1)
     T2P_WAIT(NRD, fa0, fb0)
     T2P_MMA(fa0, fb0)
