@@ -164,6 +164,9 @@ int t2p_op_gemm(int dtype, const void* A, int a_f32, const void* Bw, void* C, in
   API_END
 }
 
+static void* g_op_ws = nullptr;
+static size_t g_op_ws_bytes = 0;
+
 int t2p_op_conv3x3(int dtype, const void* x, int a_f32, const void* w, const float* bias, float* out, int batch, int H,
                    int W, int Cin, int Cout, int upsample, void* stream) {
   API_BEGIN
@@ -171,6 +174,10 @@ int t2p_op_conv3x3(int dtype, const void* x, int a_f32, const void* w, const flo
   p.dtype = dtype; p.A0 = x; p.a_f32 = a_f32; p.C0 = Cin; p.lda0 = Cin; p.taps = 9; p.H = H; p.W = W; p.a_up = upsample;
   p.Bw = w; p.ldb = 9L * Cin; p.M = batch * H * W; p.N = Cout; p.bias_n = bias; p.rows_per_batch = H * W;
   p.C = out; p.c_f32 = 1; p.ldc = Cout;
+  if (g_op_ws_bytes) {   // development switch (t2p_debug_set key 10): lets the op entry take the split-K path
+    if (!g_op_ws) T2P_HIP_CHECK(hipMalloc(&g_op_ws, g_op_ws_bytes));
+    p.ws = g_op_ws; p.ws_bytes = g_op_ws_bytes;
+  }
   return launch_gemm(p, (hipStream_t)stream);
   API_END
 }
@@ -324,6 +331,8 @@ int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int
 }
 
 int t2p_debug_set(int key, int value) {
+  if (key == 10) { g_op_ws_bytes = (size_t)value << 20; return T2P_OK; }
+  if (key == 11) { set_gemm_force_nsplit(value); return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) set_gemm_debug(value);
   else if (key == 2) set_gemm_geom(value);

@@ -295,6 +295,27 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define T2P_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 static constexpr unsigned DMA_OOB = 0x80000000u;   // >= any num_records we accept -> zeros
 
+// erf-GELU for the fused GEGLU epilogue (16-bit outputs only): Abramowitz-Stegun 7.1.26, |error| of
+// erf <= 1.5e-7 -- far below the fp16 / bf16 rounding of the result -- in a dozen VALU operations
+// instead of the branchy libm erff.
+__device__ inline float gelu_erf_fast(float g) {
+  const float x = g * 0.70710678118654752440f, ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  float q = fmaf(t, 1.061405429f, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
+  const float erf_abs = fmaf(-q * t, e, 1.f);
+  return 0.5f * g * (1.f + copysignf(erf_abs, x));
+}
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+// two fp32 values rounded to the compute dtype, packed low / high
+template <typename TC> __device__ inline uint32_t pack2(float a, float b) {
+  const TC x = from_f32<TC>(a), y = from_f32<TC>(b);
+  return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+
 // MODE 0: plain GEMM rows; 1: 3x3 convolution; 2: 3x3 convolution reading a half-resolution source
 //
 // Geometries (BM x BN block, WM x WN wavefronts, NST ring stages):
@@ -322,6 +343,90 @@ __device__ inline bool g_stagger_dbg(int dbg) { return (dbg & 128) == 0; }   // 
 template <int I> __device__ inline void lds_read_b128_2k(u32x4_t& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(I * 2048));
 }
+
+// Read-back half of the lean epilogue for one 64 x 64 slab, specialised at compile time so that the
+// loop is branch-free: 8 LDS reads and (HAS_R) 8 residual loads at a time are in flight before the
+// first use.  OUT: 0 fp32, 1 compute dtype, 2 GEGLU (interleaved value / gate columns ->
+// compute dtype), 3 raw split-K partial.  Every variant issues exactly 16 stores.
+template <typename TC, int OUT, bool HAS_R, bool STATS>
+__device__ __forceinline__ void lean_slab(const float* sp, const __amdgpu_buffer_rsrc_t rC, const __amdgpu_buffer_rsrc_t rR,
+                                          unsigned voc, const unsigned stc, unsigned vor, const unsigned str,
+                                          const float4 bn0, const float4 bn1, const int row_first, const int b_edge,
+                                          const float alpha, float* stats_dst) {
+  if constexpr (OUT == 3) {
+#pragma unroll
+    for (int h8 = 0; h8 < 2; ++h8) {
+      f32x4_t v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = *(const f32x4_t*)(sp + (h8 * 8 + i) * 256);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v[i]), rC, voc, 0, 0);
+        voc += stc;
+      }
+    }
+    return;
+  }
+  float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f, cq0 = 0.f, cq1 = 0.f, cq2 = 0.f, cq3 = 0.f;
+#pragma unroll
+  for (int h8 = 0; h8 < 2; ++h8) {
+    f32x4_t v[8], rv[8];
+    if constexpr (!HAS_R) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = *(const f32x4_t*)(sp + (h8 * 8 + i) * 256);
+    }
+    if constexpr (HAS_R) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        rv[i] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rR, vor, 0, 0));
+        vor += str;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int it = h8 * 8 + i;
+      if constexpr (HAS_R) {                          // 8 residual rows in flight, LDS reads 4 at a time (register budget)
+        if (i % 4 == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[i + k] = *(const f32x4_t*)(sp + (it + k) * 256);
+        }
+      }
+      const bool second = row_first + 4 * it >= b_edge;
+      float a0 = v[i][0] + (second ? bn1.x : bn0.x), a1 = v[i][1] + (second ? bn1.y : bn0.y);
+      float a2 = v[i][2] + (second ? bn1.z : bn0.z), a3 = v[i][3] + (second ? bn1.w : bn0.w);
+      if constexpr (HAS_R) { a0 += rv[i][0]; a1 += rv[i][1]; a2 += rv[i][2]; a3 += rv[i][3]; }
+      if constexpr (OUT == 2) {
+        // columns are interleaved (value_j, gate_j): out[row][col / 2 + {0, 1}] = value * gelu_erf(gate)
+        // (GEGLU.forward, reference model/attention.py:42-44), stored in the compute dtype
+        __builtin_amdgcn_raw_buffer_store_b32(pack2<TC>(a0 * gelu_erf_fast(a1), a2 * gelu_erf_fast(a3)), rC, voc, 0, 0);
+      } else {
+        a0 *= alpha; a1 *= alpha; a2 *= alpha; a3 *= alpha;
+        if constexpr (STATS) {
+          cs0 += a0; cs1 += a1; cs2 += a2; cs3 += a3;
+          cq0 += a0 * a0; cq1 += a1 * a1; cq2 += a2 * a2; cq3 += a3 * a3;
+        }
+        if constexpr (OUT == 0) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (f32x4_t){a0, a1, a2, a3}), rC, voc, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){pack2<TC>(a0, a1), pack2<TC>(a2, a3)}, rC, voc, 0, 0);
+        }
+      }
+      voc += stc;
+    }
+  }
+  if constexpr (STATS) {
+    // lanes l, l+16, l+32, l+48 hold the same 4 columns -> two wavefront shuffles; fixed order, reproducible
+    cs0 += __shfl_xor(cs0, 16, 64); cs1 += __shfl_xor(cs1, 16, 64); cs2 += __shfl_xor(cs2, 16, 64); cs3 += __shfl_xor(cs3, 16, 64);
+    cq0 += __shfl_xor(cq0, 16, 64); cq1 += __shfl_xor(cq1, 16, 64); cq2 += __shfl_xor(cq2, 16, 64); cq3 += __shfl_xor(cq3, 16, 64);
+    cs0 += __shfl_xor(cs0, 32, 64); cs1 += __shfl_xor(cs1, 32, 64); cs2 += __shfl_xor(cs2, 32, 64); cs3 += __shfl_xor(cs3, 32, 64);
+    cq0 += __shfl_xor(cq0, 32, 64); cq1 += __shfl_xor(cq1, 32, 64); cq2 += __shfl_xor(cq2, 32, 64); cq3 += __shfl_xor(cq3, 32, 64);
+    if (stats_dst) {
+      *(float4*)stats_dst = make_float4(cs0, cq0, cs1, cq1);
+      *(float4*)(stats_dst + 4) = make_float4(cs2, cq2, cs3, cq3);
+    }
+  }
+}
+
 
 // MF16: use v_mfma_f32_16x16x32 (sustains a higher clock than 32x32x16 at equal cycles per FLOP in
 // LDS-fed loops, MI355X_MICROARCH.md "DVFS give-back" item 7) -- 128 x 64 wave tiles only.
@@ -655,11 +760,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   const int cq = (lane & 15) * 4;                     // this lane's 4 columns inside a 64-column slab
   float* ws = nsplit > 1 ? (float*)p.ws + (long)ks * p.M * p.N : nullptr;
 
+  // Lean path (every hot launch): operands addressed through buffer descriptors -- 32-bit per-lane
+  // byte offsets bumped by a constant per 4-row step, rows past M dropped / zero-filled by the range
+  // check -- and no per-row integer division.  The generic loop further down keeps the rare cases
+  // (row bias, up-sampled residual, samples shorter than a tile, unaligned strides, >= 2 GiB operands).
+  const int c_cols = p.geglu ? p.N / 2 : p.N;
+  const long c_bytes = ws ? (long)p.M * p.N * 4 : ((long)(p.M - 1) * p.ldc + c_cols) * (p.c_f32 ? 4 : 2);
+  const long r_bytes = R ? ((long)(p.M - 1) * p.ldr + p.N) * 4 : 0;
+  const bool lean = !(dbg & 512) && (p.N & 3) == 0 && c_bytes < (1L << 31) && r_bytes < (1L << 31) &&
+                    (ws != nullptr || (!p.bias_m && !p.r_up && (!need_b || rpb >= BM) && (p.geglu ? p.ldc % 2 == 0 : p.ldc % 4 == 0) &&
+                                       (!R || p.ldr % 4 == 0) && (!p.bias_bn || p.ld_bn % 4 == 0)));
+  const __amdgpu_buffer_rsrc_t rC =
+      make_rsrc(ws ? (const void*)ws : (p.c_f32 ? (const void*)((float*)p.C + coff) : (const void*)((TC*)p.C + coff)), lean ? (int)c_bytes : 0);
+  const __amdgpu_buffer_rsrc_t rR = make_rsrc(R ? (const void*)R : (const void*)p.C, lean ? (int)r_bytes : 0);
+  const bool two_b = p.bias_bn && b_edge < m0 + BM && b_edge < p.M;   // the tile spans two samples
+
 #pragma unroll
   for (int hi = 0; hi < TI / 2; ++hi)                 // 64-row slabs of the wave tile
 #pragma unroll
     for (int hj = 0; hj < TJ / 2; ++hj) {             // 64-column slabs
       if (hi + hj > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // previous slab fully read back
+      if (!(dbg & 2048)) {
       if constexpr (MF16) {
         // 16x16 accumulator: column = lane & 15, row = (lane >> 4) * 4 + register
 #pragma unroll
@@ -678,9 +799,46 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
             for (int v = 0; v < 16; ++v)
               stg[(i * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh) * 64 + j * 32 + lr] = acc[2 * hi + i][2 * hj + j][v];
       }
+      }
       // same-wave LDS write -> read: the compiler orders them (lgkmcnt); no barrier needed
       const int row0 = m0 + wm * (BM / WM) + hi * 64;
       const int col = n0 + wn * (BN / WN) + hj * 64 + cq;
+      if (lean) {
+        const int rq = lane >> 4;
+        const bool col_ok = col < p.N;                // N % 4 == 0: the lane's 4 columns are in or out together
+        const float* sp = stg + rq * 64 + cq;
+        const unsigned esz = (ws || p.c_f32) ? 4u : 2u;
+        const unsigned ldc_e = ws ? (unsigned)p.N : (unsigned)p.ldc;
+        const unsigned voc = (col_ok && !(dbg & 1024)) ? ((unsigned)(row0 + rq) * ldc_e + (unsigned)(p.geglu ? col >> 1 : col)) * esz : DMA_OOB;
+        const unsigned stc = 4u * ldc_e * esz;
+        const unsigned vor = col_ok ? ((unsigned)(row0 + rq) * (unsigned)p.ldr + (unsigned)col) * 4u : DMA_OOB;
+        const unsigned str = 16u * (unsigned)p.ldr;
+        float4 bn0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!ws && p.bias_n && col_ok) bn0 = *(const float4*)(p.bias_n + col);
+        float4 bn1 = bn0;
+        if (!ws && p.bias_bn && col_ok) {
+          const float4 t = *(const float4*)(p.bias_bn + (long)b_first * p.ld_bn + col);
+          bn0.x += t.x; bn0.y += t.y; bn0.z += t.z; bn0.w += t.w;
+          if (two_b) {
+            const float4 u = *(const float4*)(p.bias_bn + (long)(b_first + 1) * p.ld_bn + col);
+            bn1.x += u.x; bn1.y += u.y; bn1.z += u.z; bn1.w += u.w;
+          }
+        }
+        const int edge = two_b ? b_edge : 0x7fffffff;
+        float* sd = (p.col_stats && lane < 16 && col_ok && row0 < p.M) ? p.col_stats + ((long)(row0 >> 6) * p.N + col) * 2 : nullptr;
+#define T2P_LEAN(OUT, HR, ST) lean_slab<TC, OUT, HR, ST>(sp, rC, rR, voc, stc, vor, str, bn0, bn1, row0 + rq, edge, p.alpha, sd)
+        if (ws) T2P_LEAN(3, false, false);
+        else if (p.geglu) T2P_LEAN(2, false, false);
+        else if (p.c_f32) {
+          if (R) { if (p.col_stats) T2P_LEAN(0, true, true); else T2P_LEAN(0, true, false); }
+          else { if (p.col_stats) T2P_LEAN(0, false, true); else T2P_LEAN(0, false, false); }
+        } else {
+          if (R) { if (p.col_stats) T2P_LEAN(1, true, true); else T2P_LEAN(1, true, false); }
+          else { if (p.col_stats) T2P_LEAN(1, false, true); else T2P_LEAN(1, false, false); }
+        }
+#undef T2P_LEAN
+        continue;
+      }
       if (ws) {                                       // split-K: raw partial sums -> workspace [split][M][N]
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
@@ -849,6 +1007,8 @@ static int g_dma_ring = 2;
 void set_gemm_ring(int v) { g_dma_ring = v; }
 static int g_dma_geom = 0;   // 0 auto, 1 force 256x128x3, 2 force 128x128x2, 3 force 256x256x2
 static bool g_splitk = true;
+static int g_force_nsplit = 0;   // development: > 0 forces that split-K factor wherever a workspace is attached
+void set_gemm_force_nsplit(int v) { g_force_nsplit = v; }
 static bool g_use_dma = true;
 static int g_dbg = 0;   // timing-only ablations (results are wrong when non-zero): 1 no epilogue, 2 no DMA in loop, 4 no reads/MFMA
 void set_gemm_dma(bool on) { g_use_dma = on; }
@@ -904,6 +1064,7 @@ static bool dma_uses_splitk(const GemmParams& p) {
   const int BM = g == 2 ? 128 : (g == 3 ? 512 : 256), BN = g == 1 ? 256 : 128;
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps;
+  if (g_force_nsplit > 0) return p.ws && p.nz0 * p.nz1 == 1 && g_force_nsplit > 1 && nk >= 2 * g_force_nsplit;
   return g_splitk && p.ws && p.nz0 * p.nz1 == 1 && tiles < 192 && nk >= 16;
 }
 
@@ -965,6 +1126,7 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
   const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps;
   if (dma_uses_splitk(p)) {
     nsplit = std::min(std::min(nk / 4, (384 + tiles_m * tiles_n - 1) / (tiles_m * tiles_n)), 32);
+    if (g_force_nsplit > 0) nsplit = g_force_nsplit;
     while (nsplit > 1 && (size_t)nsplit * p.M * p.N * 4 > p.ws_bytes) --nsplit;
   }
   dim3 grid(tiles_m * tiles_n, p.nz0 * p.nz1, nsplit);

@@ -24,6 +24,9 @@ template <> struct dtype_of<f16_t> { static constexpr int value = DT_F16; };
 
 __host__ __device__ inline uint16_t f32_to_bf16_bits(float f) {
   // round-to-nearest-even; NaN stays NaN (quiet)
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(uint16_t, (__bf16)f);      // gfx950: v_cvt_pk_bf16_f32 (same rounding)
+#endif
   uint32_t u = __builtin_bit_cast(uint32_t, f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
   u += 0x7fffu + ((u >> 16) & 1u);
@@ -131,6 +134,7 @@ void set_gemm_debug(int v);
 void set_gemm_geom(int v);
 void set_gemm_ring(int v);
 void set_gemm_splitk(bool on);
+void set_gemm_force_nsplit(int v);
 extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible
 extern bool g_lowp_h1;         // engine: block-internal conv0 output stored in the compute dtype
 extern bool g_fuse_geglu;      // engine: GEGLU gating inside the ff1 GEMM epilogue

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--geom", type=int, default=0)
     ap.add_argument("--ring", type=int, default=0)
     ap.add_argument("--no-dma", action="store_true")
+    ap.add_argument("--c16", action="store_true", help="1x1 GEMM: compute-dtype output instead of fp32")
+    ap.add_argument("--nsplit", type=int, default=0, help="force this split-K factor (conv only; attaches a workspace)")
     a = ap.parse_args()
     from text2protein_amd import _lib
     lib = _lib.load()
@@ -34,12 +36,15 @@ def main():
     lib.t2p_debug_set(2, a.geom)
     lib.t2p_debug_set(8, a.ring)
     lib.t2p_debug_set(0, 0 if a.no_dma else 1)
+    if a.nsplit:
+        lib.t2p_debug_set(10, 1024)
+        lib.t2p_debug_set(11, a.nsplit)
     td = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[dt]
     g = torch.Generator(device="cuda").manual_seed(0)
     x = torch.randn(a.B, a.H, a.W, a.cin, device="cuda", generator=g).to(td)
     w = (torch.randn(a.cout, a.taps * a.cin, device="cuda", generator=g) / (a.taps * a.cin) ** 0.5).to(td)
     b = torch.zeros(a.cout, device="cuda")
-    out = torch.empty(a.B, a.H, a.W, a.cout, device="cuda")
+    out = torch.empty(a.B, a.H, a.W, a.cout, device="cuda", dtype=td if a.c16 else torch.float32)
     P = lambda t: C.c_void_p(t.data_ptr())
 
     def run():
@@ -47,7 +52,7 @@ def main():
             rc = lib.t2p_op_conv3x3(dt, P(x), int(dt == 0), P(w), P(b), P(out), a.B, a.H, a.W, a.cin, a.cout, 0, None)
         else:
             M = a.B * a.H * a.W
-            rc = lib.t2p_op_gemm(dt, P(x), int(dt == 0), P(w), P(out), 1, M, a.cout, a.cin, a.cin, a.cin, a.cout, P(b), None, 1.0, None)
+            rc = lib.t2p_op_gemm(dt, P(x), int(dt == 0), P(w), P(out), 0 if a.c16 else 1, M, a.cout, a.cin, a.cin, a.cin, a.cout, P(b), None, 1.0, None)
         assert rc == 0, lib.t2p_last_error()
 
     for _ in range(3):
@@ -60,8 +65,9 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.iters
+    c16 = " c16" if a.c16 else ""
     fl = 2.0 * a.B * a.H * a.W * a.cout * a.taps * a.cin
-    print(f"{a.dtype} B{a.B} {a.H}x{a.W} cin{a.cin} cout{a.cout} taps{a.taps} dbg{a.dbg} geom{a.geom} ring{a.ring}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s", flush=True)
+    print(f"{a.dtype} B{a.B} {a.H}x{a.W} cin{a.cin} cout{a.cout} taps{a.taps} dbg{a.dbg} geom{a.geom} ring{a.ring} nsplit{a.nsplit}{c16}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":
