@@ -310,3 +310,31 @@ def test_dma_issue_order_does_not_change_results(lib, geom, ring):
         lib.t2p_debug_set(1, 0)
         lib.t2p_debug_set(2, 0)
         lib.t2p_debug_set(8, 2)
+
+
+def test_conv_midsize_splitk_plan(lib):
+    """M = 8192, N = 512, K = 9 x 256 with a split-K workspace attached (development key 10): planned as
+    64 tiles of 256x256 x 4 K-splits + the vectorised second pass (bias applied there); fp64 reference."""
+    try:
+        check(lib, lib.t2p_debug_set(10, 256))
+        g = torch.Generator().manual_seed(123)
+        B, H, W, Cin, Cout = 32, 16, 16, 256, 512
+        for dt in (1, 2):
+            td = TDT[dt]
+            x = torch.randn(B, Cin, H, W, generator=g).to(td)
+            w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(td)
+            b = torch.randn(Cout, generator=g)
+            ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+            outs = []
+            for mid in (1, 0):
+                check(lib, lib.t2p_debug_set(12, mid))
+                out = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+                check(lib, lib.t2p_op_conv3x3(dt, P(dev(x.permute(0, 2, 3, 1))), 0, P(dev(w.permute(0, 2, 3, 1))), P(dev(b)), P(out),
+                                              B, H, W, Cin, Cout, 0, None))
+                torch.cuda.synchronize()
+                assert rel_l2(out.cpu(), ref) < 3e-6, (dt, mid)
+                outs.append(out.cpu())
+            assert not torch.equal(outs[0], outs[1])     # the two plans sum in different orders
+    finally:
+        lib.t2p_debug_set(10, 0)
+        lib.t2p_debug_set(12, 1)

@@ -333,6 +333,7 @@ int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int
 int t2p_debug_set(int key, int value) {
   if (key == 10) { g_op_ws_bytes = (size_t)value << 20; return T2P_OK; }
   if (key == 11) { set_gemm_force_nsplit(value); return T2P_OK; }
+  if (key == 12) { set_gemm_midsplit(value != 0); return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) set_gemm_debug(value);
   else if (key == 2) set_gemm_geom(value);

@@ -477,7 +477,7 @@ int Engine::finalize() {
 // every GEMM of the engine: lends the split-K workspace (fp32 partial tiles of low-resolution levels)
 int Engine::attach_ws(GemmParams& p) {
   if (!splitk_ws_) {
-    splitk_ws_bytes_ = (size_t)64 << 20;
+    splitk_ws_bytes_ = (size_t)256 << 20;
     splitk_ws_ = pool_.persistent(splitk_ws_bytes_);
     if (!splitk_ws_) return T2P_ERR_HIP;
   }

@@ -1054,18 +1054,130 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
   }
 }
 
+// Vectorised second pass: a 256-thread block owns RPT*16 rows x 64 columns; thread (rl = t >> 4, cg = t & 15)
+// sums the partials of 4 columns of rows rl + 16 i in split order (bitwise reproducible), applies the
+// epilogue and, with RPT == 4 (64-row blocks = the statistics chunk), the GroupNorm column statistics of
+// the final fp32 values, folded over the 16 row lanes in a fixed order through LDS.
+template <typename TC, int RPT>
+__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmParams p, const int nsplit) {
+  __shared__ float red[16][16][8];
+  const int t = threadIdx.x, cg = t & 15, rl = t >> 4;
+  const int col = blockIdx.x * 64 + cg * 4;
+  const int row0 = blockIdx.y * (RPT * 16);
+  const long total = (long)p.M * p.N;
+  const int HW = p.H * p.W;
+  const bool col_ok = col < p.N;
+  float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias_n && col_ok) bn = *(const float4*)(p.bias_n + col);
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int row = row0 + rl + 16 * i;
+    if (row >= p.M || !col_ok) continue;
+    const float* src = (const float*)p.ws + (long)row * p.N + col;
+    float4 a = *(const float4*)src;
+    for (int k = 1; k < nsplit; ++k) {
+      const float4 b = *(const float4*)(src + (long)k * total);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const int bidx = row / p.rows_per_batch;
+    long rrow = row;
+    if (p.r_up) {
+      const int rem = row - bidx * HW;
+      const int y = rem / p.W, x = rem - y * p.W;
+      rrow = ((long)bidx * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
+    }
+    const float bm = p.bias_m ? p.bias_m[row] : 0.f;
+    a.x += bm + bn.x; a.y += bm + bn.y; a.z += bm + bn.z; a.w += bm + bn.w;
+    if (p.bias_bn) {
+      const float4 b = *(const float4*)(p.bias_bn + (long)bidx * p.ld_bn + col);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if (p.R) {
+      const float4 b = *(const float4*)(p.R + rrow * p.ldr + col);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    a.x *= p.alpha; a.y *= p.alpha; a.z *= p.alpha; a.w *= p.alpha;
+    cs[0] += a.x; cs[1] += a.y; cs[2] += a.z; cs[3] += a.w;
+    cq[0] += a.x * a.x; cq[1] += a.y * a.y; cq[2] += a.z * a.z; cq[3] += a.w * a.w;
+    if (p.c_f32) *(float4*)((float*)p.C + (long)row * p.ldc + col) = a;
+    else *(u32x2_t*)((TC*)p.C + (long)row * p.ldc + col) = (u32x2_t){pack2<TC>(a.x, a.y), pack2<TC>(a.z, a.w)};
+  }
+  if (RPT == 4 && p.col_stats) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { red[rl][cg][2 * k] = cs[k]; red[rl][cg][2 * k + 1] = cq[k]; }
+    __syncthreads();
+    if (rl == 0 && col_ok && row0 < p.M) {
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = red[0][cg][k];
+      for (int r = 1; r < 16; ++r)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] += red[r][cg][k];
+      float* dst = p.col_stats + ((long)(row0 >> 6) * p.N + col) * 2;
+      *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+      *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+  }
+}
+
 void set_gemm_splitk(bool on) { g_splitk = on; }
 
 void set_gemm_geom(int v) { g_dma_geom = v; }
 
-static int dma_pick_geom(const GemmParams& p);
-static bool dma_uses_splitk(const GemmParams& p) {
-  const int g = dma_pick_geom(p);
-  const int BM = g == 2 ? 128 : (g == 3 ? 512 : 256), BN = g == 1 ? 256 : 128;
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+// Tile geometry (0: 256x128x3, 1: 256x256x2, 2: 128x128x2, 3: 512x128x2) and split-K factor of a launch.
+struct DmaPlan { int geom, nsplit; };
+static bool g_midsplit = true;   // mid-size problems: 256x256 tiles + split-K instead of 128x128 tiles
+void set_gemm_midsplit(bool on) { g_midsplit = on; }
+
+static DmaPlan dma_plan(const GemmParams& p) {
+  const long z = (long)p.nz0 * p.nz1;
   const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps;
-  if (g_force_nsplit > 0) return p.ws && p.nz0 * p.nz1 == 1 && g_force_nsplit > 1 && nk >= 2 * g_force_nsplit;
-  return g_splitk && p.ws && p.nz0 * p.nz1 == 1 && tiles < 192 && nk >= 16;
+  const bool can_split = p.ws && z == 1;
+  auto fits = [&](int ns) { return (size_t)ns * p.M * p.N * 4 <= p.ws_bytes; };
+  const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * z;
+  int geom;
+  if (g_dma_geom == 1) geom = 0;
+  else if (g_dma_geom == 2) geom = 2;
+  else if (g_dma_geom == 3) geom = 1;
+  else if (p.M < 256) geom = 2;
+  else {
+    // largest tile that still gives about one workgroup per CU: big tiles are 15-20 % more efficient
+    // (860-1020 vs 710-830 TFLOP/s on the conv shapes), but a short problem spread over few
+    // workgroups is latency-bound and finishes sooner with more, smaller tiles
+    const long t128 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * z;
+    const long t512 = (long)((p.M + 511) / 512) * ((p.N + 127) / 128) * z;
+    if (g_dma_geom == 5) geom = (p.N >= 256 && p.N % 256 == 0) ? 1 : 0;   // former policy, kept for A/B
+    else if (p.N % 256 == 0 && t256 >= 200) geom = 1;
+    else if (g_dma_geom != 6 && p.N <= 128 && t512 >= 200) geom = 3;      // narrow outputs: tall tile, same 128x64 wave tile
+    else if (t128 >= 200) geom = 0;
+    else if (g_midsplit && g_splitk && !g_force_nsplit && can_split && p.N % 256 == 0 && t256 >= 48 && nk >= 32 &&
+             std::min<long>(256 / t256, nk / 8) >= 2 && fits((int)std::min<long>(256 / t256, nk / 8))) {
+      // long-K problem with 48..128 big tiles (conv at the 16x16 level of cfg2): the 128x128 geometry would
+      // run one 4-wave workgroup per CU (320-470 TFLOP/s measured); 256x256 tiles with the K loop split so
+      // that tiles x splits ~ 256 workgroups reach 570-770
+      return {1, (int)std::min<long>(256 / t256, nk / 8)};
+    }
+    else geom = 2;
+  }
+  const int BM = geom == 2 ? 128 : (geom == 3 ? 512 : 256), BN = geom == 1 ? 256 : 128;
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  int nsplit = 1;
+  if (g_force_nsplit > 0) {
+    if (can_split && g_force_nsplit > 1 && nk >= 2 * g_force_nsplit) nsplit = g_force_nsplit;
+  } else if (g_splitk && can_split && tiles < 192 && nk >= 16) {
+    // the tile grid cannot fill the chip and the K loop is long (low-resolution levels)
+    nsplit = std::min(std::min(nk / 4, (384 + tiles - 1) / tiles), 32);
+  }
+  while (nsplit > 1 && !fits(nsplit)) --nsplit;
+  return {geom, nsplit};
+}
+static bool dma_uses_splitk(const GemmParams& p) { return dma_plan(p).nsplit > 1; }
+static int dma_pick_geom(const GemmParams& p) { return dma_plan(p).geom; }
+
+// the vectorised split-K second pass (which also produces the GroupNorm column statistics) applies
+static bool splitk_reduce_vec_ok(const GemmParams& p) {
+  return p.N % 4 == 0 && p.ldc % 4 == 0 && (!p.R || p.ldr % 4 == 0) && (!p.bias_bn || p.ld_bn % 4 == 0) && !p.geglu;
 }
 
 // true when launch_gemm(p) with p.geglu set will apply the fused GEGLU epilogue
@@ -1087,27 +1199,8 @@ bool gemm_fuses_col_stats_lowp(const GemmParams& p) {
 bool gemm_fuses_col_stats(const GemmParams& p) {
   if (!dma_eligible(p) || p.nz0 * p.nz1 != 1 || !p.c_f32) return false;
   if (p.N % 4 != 0 || p.ldc % 4 != 0 || (p.R && p.ldr % 4 != 0) || (p.bias_bn && p.ld_bn % 4 != 0)) return false;
-  if (dma_uses_splitk(p)) return false;                      // split-K path writes raw partial tiles
+  if (dma_uses_splitk(p) && !splitk_reduce_vec_ok(p)) return false;   // scalar second pass: no statistics
   return p.M % 64 == 0;
-}
-
-static int dma_pick_geom(const GemmParams& p) {   // 0: 256x128x3, 1: 256x256x2, 2: 128x128x2, 3: 512x128x2
-  if (g_dma_geom == 1) return 0;
-  if (g_dma_geom == 2) return 2;
-  if (g_dma_geom == 3) return 1;
-  if (p.M < 256) return 2;
-  // largest tile that still gives about one workgroup per CU: big tiles are 15-20 % more efficient
-  // (860-1020 vs 710-830 TFLOP/s on the conv shapes), but a short problem spread over few
-  // workgroups is latency-bound and finishes sooner with more, smaller tiles
-  const long z = (long)p.nz0 * p.nz1;
-  const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * z;
-  const long t128 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128) * z;
-  if (g_dma_geom == 5) return (p.N >= 256 && p.N % 256 == 0) ? 1 : 0;   // former policy, kept for A/B
-  if (p.N % 256 == 0 && t256 >= 200) return 1;
-  const long t512 = (long)((p.M + 511) / 512) * ((p.N + 127) / 128) * z;
-  if (g_dma_geom != 6 && p.N <= 128 && t512 >= 200) return 3;            // narrow outputs: tall tile, same 128x64 wave tile
-  if (t128 >= 200) return 0;
-  return 2;
 }
 
 template <typename TC, int MODE, int BM, int BN, int WM, int WN, int NST, int NSTB = NST, bool MF16 = false>
@@ -1121,14 +1214,7 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
     attr_set = true;
   }
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  // split-K when the tile grid cannot fill the chip and the K loop is long (low-resolution levels)
-  int nsplit = 1;
-  const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps;
-  if (dma_uses_splitk(p)) {
-    nsplit = std::min(std::min(nk / 4, (384 + tiles_m * tiles_n - 1) / (tiles_m * tiles_n)), 32);
-    if (g_force_nsplit > 0) nsplit = g_force_nsplit;
-    while (nsplit > 1 && (size_t)nsplit * p.M * p.N * 4 > p.ws_bytes) --nsplit;
-  }
+  const int nsplit = dma_plan(p).nsplit;
   dim3 grid(tiles_m * tiles_n, p.nz0 * p.nz1, nsplit);
   ProfRec rec;
   if (g_prof_on) {
@@ -1140,9 +1226,17 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
   }
   hipLaunchKernelGGL(kern, grid, dim3(threads), smem, stream, p, tiles_m, tiles_n, g_dbg);
   if (nsplit > 1) {
-    const long total = (long)p.M * p.N;
-    const int g = (int)std::min<long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel<TC>, dim3(g), dim3(256), 0, stream, p, nsplit);
+    if (splitk_reduce_vec_ok(p)) {
+      // 64 x 64 output blocks when column statistics are wanted (their chunking), 16 x 64 otherwise
+      const int rows = (p.col_stats || (long)p.M * p.N >= (1L << 22)) ? 64 : 16;
+      dim3 g((p.N + 63) / 64, (p.M + rows - 1) / rows);
+      if (rows == 64) hipLaunchKernelGGL((splitk_reduce_vec_kernel<TC, 4>), g, dim3(256), 0, stream, p, nsplit);
+      else hipLaunchKernelGGL((splitk_reduce_vec_kernel<TC, 1>), g, dim3(256), 0, stream, p, nsplit);
+    } else {
+      const long total = (long)p.M * p.N;
+      const int g = (int)std::min<long>((total + 255) / 256, 4096);
+      hipLaunchKernelGGL(splitk_reduce_kernel<TC>, dim3(g), dim3(256), 0, stream, p, nsplit);
+    }
   }
   if (g_prof_on) {
     T2P_HIP_CHECK(hipEventRecord(rec.b, stream));
