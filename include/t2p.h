@@ -163,13 +163,17 @@ int t2p_op_convert(const float* in, void* out, int dtype, int64_t n, void* strea
 int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int64_t n, void* stream);
 
 /* ---- measurement hooks (bench.py): time every MFMA GEMM launch with HIP events on its stream ----
- * out6 = {conv3x3: ms, flops, launches, other GEMMs: ms, flops, launches} since t2p_profile_begin */
+ * out9 = {LDS-DMA conv3x3: ms, flops, launches; other GEMMs: ...; conv3x3 on the register-staged kernel: ...} since t2p_profile_begin */
 int t2p_profile_begin(void);
 /* development switches: key 0 = enable (1) / disable (0) the LDS-DMA GEMM kernel; key 1 = timing-only
  * ablation mask of that kernel (bits 1..64 produce wrong results; bits 128 / 256 only switch off the
  * staggered DMA issue order of the two wave halves, results unchanged; never set in product code) */
 int t2p_debug_set(int key, int value);
-int t2p_profile_end(double* out6);
+int t2p_profile_end(double* out9);
+/* after t2p_profile_end: the 3x3-convolution kernel instantiation with the largest total time in that region --
+ * out3 = {ms (main kernel only), flops, launches}, name = the kernel name as rocprofv3 reports it (no argument list),
+ * so that bench.py's live average launch duration can be checked against profiles/<round>_kernel_stats.csv */
+int t2p_profile_dominant(double* out3, char* name, int name_len);
 
 #ifdef __cplusplus
 }

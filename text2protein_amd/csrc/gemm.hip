@@ -15,6 +15,9 @@
 // LDS rows hold BK = 128 bytes of K (32 fp32 / 64 16-bit elements); a lane's fragment for
 // k-group s is the 16 bytes at [row][32 s + 16 (lane >> 5)], for both element widths.
 #include <algorithm>
+#include <array>
+#include <map>
+#include <string>
 #include <vector>
 
 #include "t2p_common.h"
@@ -947,9 +950,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
 }
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream -----------
-struct ProfRec { hipEvent_t a, b; double flops; int kind; };
+struct ProfRec { hipEvent_t a, b; double flops; int kind; const char* name; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
+// the 3x3-convolution instantiation with the largest total time of the last profiled region
+static std::string g_dom_name;
+static double g_dom[3] = {0, 0, 0};
 
 void profile_begin() {
   for (ProfRec& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -962,14 +968,31 @@ void profile_begin() {
 int profile_end(double out[3][3]) {
   g_prof_on = false;
   for (int k = 0; k < 3; ++k) out[k][0] = out[k][1] = out[k][2] = 0;
+  std::map<std::string, std::array<double, 3>> per;
   for (ProfRec& r : g_prof) {
     T2P_HIP_CHECK(hipEventSynchronize(r.b));
     float ms = 0.f;
     T2P_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
     out[r.kind][0] += ms; out[r.kind][1] += r.flops; out[r.kind][2] += 1;
+    if (r.kind == 0 && r.name) {
+      auto& e = per[r.name];
+      e[0] += ms; e[1] += r.flops; e[2] += 1;
+    }
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
   g_prof.clear();
+  g_dom_name.clear();
+  g_dom[0] = g_dom[1] = g_dom[2] = 0;
+  for (auto& kv : per)
+    if (kv.second[0] > g_dom[0]) { g_dom_name = kv.first; g_dom[0] = kv.second[0]; g_dom[1] = kv.second[1]; g_dom[2] = kv.second[2]; }
+  return T2P_OK;
+}
+
+// {milliseconds, flops, launches} and the kernel name (as rocprofv3 prints it, without the argument list) of the
+// dominant 3x3-convolution instantiation of the region closed by the last profile_end
+int profile_dominant(double out[3], const char** name) {
+  out[0] = g_dom[0]; out[1] = g_dom[1]; out[2] = g_dom[2];
+  *name = g_dom_name.c_str();
   return T2P_OK;
 }
 
@@ -989,6 +1012,7 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     T2P_HIP_CHECK(hipEventCreate(&rec.b));
     rec.flops = 2.0 * p.M * p.N * (double)p.taps * (p.C0 + p.C1) * p.nz0 * p.nz1;
     rec.kind = p.taps == 9 ? 2 : 1;
+    rec.name = nullptr;
     T2P_HIP_CHECK(hipEventRecord(rec.a, stream));
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
@@ -1222,9 +1246,15 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
     T2P_HIP_CHECK(hipEventCreate(&rec.b));
     rec.flops = 2.0 * p.M * p.N * (double)p.taps * (p.C0 + p.C1) * p.nz0 * p.nz1;
     rec.kind = p.taps == 9 ? 0 : 1;
+    static const std::string kname = std::string("gemm_dma_kernel<") + (dtype_of<TC>::value == DT_F16 ? "f16_t" : "bf16_t") + ", " +
+                                     std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) +
+                                     ", " + std::to_string(MODE) + ", " + std::to_string(NST) + ", " + std::to_string(NSTB) + ", " +
+                                     (MF16 ? "true" : "false") + ">";
+    rec.name = kname.c_str();
     T2P_HIP_CHECK(hipEventRecord(rec.a, stream));
   }
   hipLaunchKernelGGL(kern, grid, dim3(threads), smem, stream, p, tiles_m, tiles_n, g_dbg);
+  if (g_prof_on) T2P_HIP_CHECK(hipEventRecord(rec.b, stream));   // the main kernel only: comparable with rocprofv3's per-kernel average
   if (nsplit > 1) {
     if (splitk_reduce_vec_ok(p)) {
       // 64 x 64 output blocks when column statistics are wanted (their chunking), 16 x 64 otherwise
@@ -1238,10 +1268,7 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
       hipLaunchKernelGGL(splitk_reduce_kernel<TC>, dim3(g), dim3(256), 0, stream, p, nsplit);
     }
   }
-  if (g_prof_on) {
-    T2P_HIP_CHECK(hipEventRecord(rec.b, stream));
-    g_prof.push_back(rec);
-  }
+  if (g_prof_on) g_prof.push_back(rec);
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }

@@ -19,6 +19,11 @@ def short(name):
     return name.split("(")[0].replace("void t2p::", "").replace("t2p::", "")
 
 
+def newest(pattern):
+    """Scratch directories may hold files of earlier calls: take the most recent match."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", required=True)
@@ -29,9 +34,9 @@ def main():
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    ks = glob.glob(os.path.join(a.stats, "*", "*kernel_stats.csv"))[0]
+    ks = newest(os.path.join(a.stats, "*", "*kernel_stats.csv"))
     shutil.copy(ks, os.path.join(out, f"{a.tag}_kernel_stats.csv"))
-    rows = list(csv.DictReader(open(glob.glob(os.path.join(a.stats, "*", "*kernel_trace.csv"))[0])))
+    rows = list(csv.DictReader(open(newest(os.path.join(a.stats, "*", "*kernel_trace.csv")))))
     per = collections.defaultdict(lambda: [0, 0.0])
     tot = 0.0
     for r in rows:
@@ -50,7 +55,7 @@ def main():
     for kind, d in (("fetch", a.fetch), ("write", a.write)):
         if not d:
             continue
-        rr = list(csv.DictReader(open(glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0])))
+        rr = list(csv.DictReader(open(newest(os.path.join(d, "*", "*counter_collection.csv")))))
         acc = collections.defaultdict(lambda: [0, 0.0])
         for r in rr:
             nm = short(r["Kernel_Name"])
