@@ -159,6 +159,18 @@ int t2p_op_predictor(const float* x, const float* score, const float* noise, con
                      int probability_flow, void* stream);
 int t2p_op_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
 int t2p_op_convert(const float* in, void* out, int dtype, int64_t n, void* stream);
+/* ---- either side of the sampler ----
+ * 6D decode of finished samples, sampling_rosetta.py:69-96: x = (batch, channels, L, L) fp32 with the padding mask in
+ * the last channel.  lengths[b] = sqrt(#(round(mask) == 1)) or -1 when that count is not a perfect square (the
+ * reference raises ValueError); clipped / absval = (batch, 4, L*L) fp32: per channel (dist, omega, theta, phi) the
+ * first lengths[b]^2 entries are clip(x[c][mask == 1], -1, 1) in row-major order (= .reshape(L, L)) and its inverse
+ * scaling (dist+1)*10, omega*pi, theta*pi, (phi+1)*pi/2. */
+int t2p_op_decode_6d(const float* x, int batch, int channels, int L, float* clipped, float* absval, int32_t* lengths, void* stream);
+/* text context = embed_tokens(ids), sampling_6d.py:134-137: out[(b,t)][:] = table[ids[(b,t)]][:] as fp32; the table
+ * ([vocab][dim], fp32 / bf16 / f16 by table_dtype) stays resident.  *bad_flag (device int, zeroed by the caller) is
+ * set to 1 when an id falls outside [0, vocab). */
+int t2p_op_embedding_gather(const void* table, int table_dtype, const int32_t* ids, float* out, int64_t n_tokens, int dim, int vocab,
+                            int32_t* bad_flag, void* stream);
 /* x = where(mask, x, x_initial) (sampling.py:283,285,287) */
 int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int64_t n, void* stream);
 

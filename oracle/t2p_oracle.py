@@ -379,3 +379,39 @@ def selected_mask(mask_info: str, batch, n):
         else:
             m[:, int(r)] = 1
     return torch.logical_or(m.unsqueeze(-1), m.unsqueeze(1)).bool()
+
+
+# ---- either side of the sampler -------------------------------------------------
+# PARITY PINNING of this section: `sampling_rosetta.py` and the LLaMA loader of `sampling_6d.py` do
+# not import here (pyrosetta / a model fetched by name are missing: ordinary ImportError / no
+# network), so these two functions are pinned by restatement only -- they repeat the reference's
+# own numpy / torch expressions line by line.
+def decode_6d(coords_6d):
+    """sampling_rosetta.py:59-96 for one sample: `(C, L, L)` or `(1, C, L, L)`, padding mask last.
+
+    Returns the reference's ``npz`` dict (dist / omega / theta / phi and their ``*_abs`` inverse
+    scalings, each ``(L, L)`` float32) plus ``L``; raises ValueError on an improper mask (:72-73)."""
+    c = np.asarray(coords_6d, dtype=np.float32)
+    if c.ndim == 4:                                    # :59-60
+        c = c[0]
+    msk = np.round(c[-1])                              # :69   (half to even)
+    L = math.sqrt(len(msk[msk == 1]))                  # :70
+    if not L.is_integer():                             # :71-73
+        raise ValueError("Terminated due to improper masking channel...")
+    L = int(L)
+    npz = {}
+    for idx, name in enumerate(["dist", "omega", "theta", "phi"]):      # :88-89
+        npz[name] = np.clip(c[idx][msk == 1].reshape(L, L), -1, 1)
+    pi = np.float32(math.pi)                           # float32 array x Python float stays float32
+    npz["dist_abs"] = (npz["dist"] + np.float32(1)) * np.float32(10)    # :92
+    npz["omega_abs"] = npz["omega"] * pi                                # :93
+    npz["theta_abs"] = npz["theta"] * pi                                # :94
+    npz["phi_abs"] = (npz["phi"] + np.float32(1)) * pi / np.float32(2)  # :95
+    npz["L"] = L
+    return npz
+
+
+def embed_tokens(table: torch.Tensor, tokens: torch.Tensor) -> torch.Tensor:
+    """``llm.model.embed_tokens(tokens)`` (sampling_6d.py:137): an ``nn.Embedding`` row lookup; the
+    attention mask of the tokenizer is not used, padded positions carry the pad token's row."""
+    return F.embedding(tokens.long(), table.float())

@@ -9,8 +9,13 @@ contract (one pickle per sample, tensor (1, C, L, L), under
 sampling/coords_6d/<config stem>/<run>/<tag>/sampled_<id>.pkl, sampling_6d.py:160-162).
 Differences, all at the edges of the hot path:
   * text context: the reference embeds captions with a LLaMA embedding table fetched by name
-    (sampling_6d.py:121-137); offline that producer is out of scope, so the context comes from
-    ``--context <file.pt>`` (a (B, T, context_dim) float tensor) or is synthetic (``--context synthetic``).
+    (sampling_6d.py:121-137).  Here the same producer runs from local files: ``--captions <file>`` (one
+    caption per line, optionally ``id<TAB>caption``) with ``--tokenizer_path <dir>`` and ``--embed_table
+    <file or HF checkpoint dir>`` (only ``embed_tokens`` is read; the lookup is a HIP gather).  Without
+    captions the context comes from ``--context <file.pt>`` (a (B, T, context_dim) float tensor) or is
+    synthetic (``--context synthetic``).
+  * ``--decode`` additionally writes ``decoded_<id>.npz`` per sample: the reference's first folding stage
+    (sampling_rosetta.py:69-96: mask rounding, crop, clip, inverse scaling) done on the device.
   * ``--pdb`` conditions need biotite and are broken in the reference: refused.
   * ``checkpoint`` may be the word ``synthetic`` (hash-generated weights, no file needed).
   * extra flags: --dtype (f32|f16|bf16), --seed, --ids, --num_scales / --max_res_num overrides.
@@ -52,6 +57,10 @@ def main():
     parser.add_argument("--num_scales", type=int, default=None)
     parser.add_argument("--max_res_num", type=int, default=None)
     parser.add_argument("--outdir", type=str, default=None)
+    parser.add_argument("--captions", type=str, default=None, help="text file: one caption (or id<TAB>caption) per line")
+    parser.add_argument("--tokenizer_path", type=str, default=None)
+    parser.add_argument("--embed_table", type=str, default=None)
+    parser.add_argument("--decode", action="store_true", help="also write decoded_<id>.npz (sampling_rosetta.py:69-96)")
     args = parser.parse_args()
 
     assert not (args.pdb is not None and args.select_length)
@@ -108,13 +117,30 @@ def main():
     sampling_shape = (B, config.data.num_channels, config.data.max_res_num, config.data.max_res_num)
     sampling_fn = sampling.get_sampling_fn(config, sde, sampling_shape, sampling_eps, seed=args.seed * 1000 + rank)
 
-    if args.context == "synthetic":
+    caption_ids = None
+    if args.captions:
+        if not (args.tokenizer_path and args.embed_table):
+            raise SystemExit("--captions needs --tokenizer_path and --embed_table (local paths)")
+        from text2protein_amd.text_context import TextContextProducer
+        rows = [ln.rstrip("\n") for ln in open(args.captions) if ln.strip()]
+        rows = rows[rank * B:(rank + 1) * B]
+        if len(rows) != B:
+            raise SystemExit(f"--captions must hold batch_size x world_size = {B * world} captions")
+        if all("\t" in r for r in rows):
+            caption_ids = [r.split("\t", 1)[0] for r in rows]
+            rows = [r.split("\t", 1)[1] for r in rows]
+        producer = TextContextProducer.from_local(args.tokenizer_path, args.embed_table, device=device)
+        context = producer(rows)                           # sampling_6d.py:134-137
+        if context.shape[-1] != config.model.context_dim:
+            raise SystemExit(f"embedding width {context.shape[-1]} != model.context_dim {config.model.context_dim}")
+        del producer
+    elif args.context == "synthetic":
         context = synth.synth_context(B, args.context_tokens, config.model.context_dim, seed=args.seed * 1000 + rank)
     else:
         context = torch.load(args.context, map_location="cpu")
         if context.shape[0] != B:
             raise SystemExit(f"context batch {context.shape[0]} != --batch_size {B}")
-    ids = args.ids.split(",") if args.ids else [str(rank * B + i) for i in range(B)]
+    ids = args.ids.split(",") if args.ids else (caption_ids or [str(rank * B + i) for i in range(B)])
     if len(ids) != B:
         raise SystemExit("--ids must list batch_size ids")
 
@@ -141,6 +167,21 @@ def main():
                 suffix = f"_{it}" if args.n_iter > 1 else ""
                 with open(workdir.joinpath(f"sampled_{sid}{suffix}.pkl"), "wb") as f:
                     pkl.dump(generated[i].unsqueeze(0), f)
+            if args.decode:
+                import numpy as np
+                from text2protein_amd.decode import NAMES, decode_6d_batch
+                lengths, clipped, absval = decode_6d_batch(sample)
+                for i, sid in enumerate(out_ids):
+                    Lb = int(lengths[i])
+                    if Lb < 0:          # sampling_rosetta.py:72-73 raises for such a sample; here it is reported and skipped
+                        print(f"sample {sid}: improper masking channel, not decoded")
+                        continue
+                    suffix = f"_{it}" if args.n_iter > 1 else ""
+                    arrs = {}
+                    for c, nm in enumerate(NAMES):
+                        arrs[nm] = clipped[i, c, :Lb * Lb].reshape(Lb, Lb).cpu().numpy()
+                        arrs[nm + "_abs"] = absval[i, c, :Lb * Lb].reshape(Lb, Lb).cpu().numpy()
+                    np.savez(workdir.joinpath(f"decoded_{sid}{suffix}.npz"), **arrs)
             print(f"[{it + 1} / {args.n_iter}] save samples to {workdir} ({n} score evaluations per chain)")
     if dist is not None:
         dist.destroy_process_group()

@@ -9,6 +9,8 @@ import pytest
 import torch
 import yaml
 
+from test_cpu_edges import tiny_tokenizer_dir  # noqa: F401  (fixture)
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -40,3 +42,36 @@ def test_cli_roundtrip(tmp_path):
     m[:n, :n] = 1
     assert torch.equal(t[0, -1], m)                       # last channel carries the length mask
     assert torch.isfinite(t).all()
+
+
+def test_cli_captions_and_decode(tmp_path, tiny_tokenizer_dir):
+    """captions -> local tokenizer + embedding table -> context (sampling_6d.py:121-137) and --decode
+    (sampling_rosetta.py:69-96): the decoded maps equal the oracle's decode of the pickled sample."""
+    import numpy as np
+    from oracle import t2p_oracle as O
+    from text2protein_amd import checkpoint
+    from text2protein_amd.config import tiny_config
+    cfg = tiny_config(**{"model.num_scales": 3, "model.condition": ["length"]})
+    cfg_path = tmp_path / "tiny.yml"
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(yaml.safe_load(__import__("json").dumps(cfg)), f)
+    ckpt_dir = tmp_path / "training" / "tiny" / "run0" / "checkpoints"
+    ckpt_dir.mkdir(parents=True)
+    ckpt = checkpoint.save_synthetic_checkpoint(str(ckpt_dir / "best.pth"), cfg, seed=2)
+    table = torch.randn(80, cfg.model.context_dim, generator=torch.Generator().manual_seed(7))
+    torch.save({"model.embed_tokens.weight": table}, tmp_path / "pytorch_model.bin")
+    (tmp_path / "caps.txt").write_text("1abc_A\tthe protein binds atp\n2xyz_B\tmembrane transporter with twelve helices\n")
+    out = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(ROOT, "sampling_6d.py"), str(cfg_path), ckpt, "--batch_size", "2", "--dtype", "f32",
+           "--select_length", "1", "--length_index", "5", "--outdir", str(out), "--captions", str(tmp_path / "caps.txt"),
+           "--tokenizer_path", tiny_tokenizer_dir, "--embed_table", str(tmp_path / "pytorch_model.bin"), "--decode"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert sorted(os.listdir(out)) == ["decoded_1abc_A.npz", "decoded_2xyz_B.npz", "sampled_1abc_A.pkl", "sampled_2xyz_B.pkl"]
+    with open(out / "sampled_2xyz_B.pkl", "rb") as f:
+        t = pickle.load(f)
+    want = O.decode_6d(t.numpy())
+    got = np.load(out / "decoded_2xyz_B.npz")
+    assert want["L"] == cfg.data.min_res_num + 5 - 1
+    for k in ("dist", "omega", "theta", "phi", "dist_abs", "omega_abs", "theta_abs", "phi_abs"):
+        assert np.array_equal(got[k], want[k]), k

@@ -324,6 +324,19 @@ int t2p_op_convert(const float* in, void* out, int dtype, int64_t n, void* strea
   API_END
 }
 
+int t2p_op_decode_6d(const float* x, int batch, int channels, int L, float* clipped, float* absval, int32_t* lengths, void* stream) {
+  API_BEGIN
+  return launch_decode6d(x, batch, channels, L, clipped, absval, lengths, (hipStream_t)stream);
+  API_END
+}
+
+int t2p_op_embedding_gather(const void* table, int table_dtype, const int32_t* ids, float* out, int64_t n_tokens, int dim, int vocab,
+                            int32_t* bad_flag, void* stream) {
+  API_BEGIN
+  return launch_embedding_gather(table, table_dtype, ids, out, n_tokens, dim, vocab, bad_flag, (hipStream_t)stream);
+  API_END
+}
+
 int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int64_t n, void* stream) {
   API_BEGIN
   return launch_apply_mask(x, mask, x_initial, n, (hipStream_t)stream);

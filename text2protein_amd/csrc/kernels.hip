@@ -818,4 +818,98 @@ int launch_apply_mask(float* x, const unsigned char* mask, const float* x_initia
   return T2P_OK;
 }
 
+// ================================== after the sampler: 6D decode ====================================
+// sampling_rosetta.py:69-96 for one sample per workgroup: msk = round(x[-1]) (half to even);
+// n1 = #(msk == 1) must be a perfect square L^2, else length = -1 (the reference raises ValueError);
+// channel c < 4: clip(x[c][msk == 1], -1, 1) compacted in row-major order (= .reshape(L, L)), then the
+// inverse scaling dist = (d + 1) * 10, omega / theta = v * pi, phi = (v + 1) * pi / 2 in fp32, in the
+// reference's operation order.  The compaction offset is a block-wide exclusive scan of per-thread
+// counts (each thread owns one contiguous run of the flattened map, so the order is preserved).
+__global__ __launch_bounds__(1024) void decode6d_kernel(const float* x, int C, int n, float* clipped, float* absval, int* lengths) {
+  __shared__ int part[1024];
+  __shared__ int total_s;
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* xs = x + (long)b * C * n;
+  const float* mk = xs + (long)(C - 1) * n;
+  const int per = (n + 1023) / 1024;
+  const int lo = min(t * per, n), hi = min(lo + per, n);
+  int cnt = 0;
+  for (int i = lo; i < hi; ++i) cnt += rintf(mk[i]) == 1.0f;
+  part[t] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {          // inclusive Hillis-Steele scan
+    const int v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  if (t == 1023) total_s = part[1023];
+  __syncthreads();
+  const int total = total_s;
+  int L = (int)sqrtf((float)total);
+  while (L * L > total) --L;
+  while ((L + 1) * (L + 1) <= total) ++L;
+  const bool proper = L * L == total;
+  if (t == 0) lengths[b] = proper ? L : -1;
+  if (!proper) return;
+  int o = part[t] - cnt;                              // exclusive prefix = this thread's first output slot
+  const float PI_F = 3.14159274101257324f;            // float32(math.pi)
+  float* cl = clipped + (long)b * 4 * n;
+  float* ab = absval + (long)b * 4 * n;
+  for (int i = lo; i < hi; ++i) {
+    if (rintf(mk[i]) != 1.0f) continue;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float v = fminf(fmaxf(xs[(long)c * n + i], -1.f), 1.f);
+      float a;
+      if (c == 0) a = (v + 1.f) * 10.f;
+      else if (c == 3) a = ((v + 1.f) * PI_F) / 2.f;
+      else a = v * PI_F;
+      cl[(long)c * n + o] = v;
+      ab[(long)c * n + o] = a;
+    }
+    ++o;
+  }
+}
+int launch_decode6d(const float* x, int B, int C, int L, float* clipped, float* absval, int* lengths, hipStream_t s) {
+  T2P_REQUIRE(x && clipped && absval && lengths && B > 0 && C >= 5 && L > 0, "decode_6d arguments (needs 4 geometry channels + the mask channel)");
+  T2P_REQUIRE((long)L * L < (1L << 30), "map too large");
+  hipLaunchKernelGGL(decode6d_kernel, dim3(B), dim3(1024), 0, s, x, C, L * L, clipped, absval, lengths);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// ================================== before the sampler: text context ================================
+// context[b, t, :] = table[ids[b, t], :]  (llm.model.embed_tokens(tokens), reference sampling_6d.py:137;
+// modeling_llama nn.Embedding).  One wavefront per token, 16-byte lanes; fp32 output (the sampler's
+// context dtype), table in fp32 or in a 16-bit dtype.  An id outside the table is an error reported
+// through `bad` (device flag), like torch's index check.
+template <typename TT>
+__global__ __launch_bounds__(256) void embedding_gather_kernel(const TT* table, const int* ids, float* out, long ntok, int dim, int vocab, int* bad) {
+  const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= ntok) return;
+  const int lane = threadIdx.x & 63;
+  const int id = ids[tok];
+  if (id < 0 || id >= vocab) { if (lane == 0) atomicExch(bad, 1); return; }
+  const TT* src = table + (long)id * dim;
+  float* dst = out + tok * dim;
+  for (int c = lane * 4; c < dim; c += 256) {
+    const float4 v = load4<TT>(src + c);
+    *(float4*)(dst + c) = v;
+  }
+}
+int launch_embedding_gather(const void* table, int dtype, const int* ids, float* out, long ntok, int dim, int vocab, int* bad, hipStream_t s) {
+  T2P_REQUIRE(table && ids && out && bad && ntok > 0 && vocab > 0, "embedding_gather arguments");
+  T2P_REQUIRE(dim > 0 && dim % 4 == 0, "embedding width must be a multiple of 4");
+  dim3 grid((unsigned)((ntok + 3) / 4));
+  switch (dtype) {
+    case DT_F32: hipLaunchKernelGGL(embedding_gather_kernel<float>, grid, dim3(256), 0, s, (const float*)table, ids, out, ntok, dim, vocab, bad); break;
+    case DT_BF16: hipLaunchKernelGGL(embedding_gather_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)table, ids, out, ntok, dim, vocab, bad); break;
+    case DT_F16: hipLaunchKernelGGL(embedding_gather_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)table, ids, out, ntok, dim, vocab, bad); break;
+    default: set_last_error("embedding_gather: bad dtype"); return T2P_ERR_INVALID;
+  }
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
 }  // namespace t2p

@@ -108,5 +108,7 @@ int launch_convert(const float* in, void* out, int dtype, long n, hipStream_t s)
 int launch_gather_label(const int* labels, const int* step_counter, const float* table, float* out, int B, int N,
                         hipStream_t s);
 int launch_apply_mask(float* x, const unsigned char* mask, const float* x_initial, long n, hipStream_t s);
+int launch_decode6d(const float* x, int B, int C, int L, float* clipped, float* absval, int* lengths, hipStream_t s);
+int launch_embedding_gather(const void* table, int dtype, const int* ids, float* out, long ntok, int dim, int vocab, int* bad, hipStream_t s);
 
 }  // namespace t2p
