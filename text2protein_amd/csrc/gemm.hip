@@ -1099,8 +1099,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmParams
     const int row = row0 + rl + 16 * i;
     if (row >= p.M || !col_ok) continue;
     const float* src = (const float*)p.ws + (long)row * p.N + col;
-    float4 a = *(const float4*)src;
-    for (int k = 1; k < nsplit; ++k) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);       // 0 + p0 is exact: same sums as starting from p0
+    int k = 0;
+    for (; k + 8 <= nsplit; k += 8) {                 // 8 partial loads in flight, added in split order
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *(const float4*)(src + (long)(k + j) * total);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+    }
+    for (; k + 2 <= nsplit; k += 2) {
+      const float4 b0 = *(const float4*)(src + (long)k * total), b1 = *(const float4*)(src + (long)(k + 1) * total);
+      a.x += b0.x; a.y += b0.y; a.z += b0.z; a.w += b0.w;
+      a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+    }
+    if (k < nsplit) {
       const float4 b = *(const float4*)(src + (long)k * total);
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
