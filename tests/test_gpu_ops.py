@@ -100,8 +100,9 @@ def test_conv3x3(lib, dt, B, H, W, Cin, Cout, up):
 
 @pytest.mark.parametrize("C0,C1,G,silu,down", [(32, 0, 8, 1, 0), (64, 32, 24, 1, 0), (512, 256, 32, 0, 0),
                                                (64, 0, 16, 1, 1), (1024, 1024, 32, 1, 0), (1024, 512, 32, 0, 0)])
-def test_groupnorm(lib, C0, C1, G, silu, down):
-    B, H, W = 2, 8, 6
+@pytest.mark.parametrize("H,W", [(8, 6), (16, 12)])     # <= 64 pixels: single-launch kernel; larger: statistics / finalize / apply
+def test_groupnorm(lib, C0, C1, G, silu, down, H, W):
+    B = 2
     g = torch.Generator().manual_seed(C0 + C1)
     x = torch.randn(B, C0 + C1, H, W, generator=g) * 2 + 0.5
     gamma = torch.randn(C0 + C1, generator=g)

@@ -190,6 +190,12 @@ int t2p_op_groupnorm(const float* x0, const float* x1, int C0, int C1, int batch
   GroupNormArgs a;
   a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.B = batch; a.HW = H * W; a.G = groups; a.eps = eps;
   const int C = C0 + C1;
+  {
+    GroupNormApplyArgs g;
+    g.x0 = x0; g.x1 = x1; g.C0 = C0; g.C1 = C1; g.B = batch; g.H = H; g.W = W; g.G = groups; g.gamma = gamma; g.beta = beta;
+    g.silu = silu; g.down = down; g.out = out; g.dtype = dtype; g.eps = eps;
+    if (g_gn_small && gn_small_eligible(g)) return launch_gn_small(g, s);
+  }
   const int nparts = gn_num_chunks(a.HW) * ((C + 1023) / 1024);
   float* ws = nullptr;
   T2P_HIP_CHECK(hipMalloc((void**)&ws, ((size_t)batch * nparts * groups * 2 + (size_t)batch * groups * 2) * 4));
@@ -347,6 +353,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 10) { g_op_ws_bytes = (size_t)value << 20; return T2P_OK; }
   if (key == 11) { set_gemm_force_nsplit(value); return T2P_OK; }
   if (key == 12) { set_gemm_midsplit(value != 0); return T2P_OK; }
+  if (key == 13) { g_gn_small = value != 0; return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) set_gemm_debug(value);
   else if (key == 2) set_gemm_geom(value);

@@ -14,6 +14,7 @@ namespace t2p {
 bool g_fuse_gn_stats = true;
 bool g_fuse_geglu = true;
 bool g_lowp_h1 = true;
+bool g_gn_small = true;
 bool g_raw_copies = true;
 bool g_flash_attention = true;
 static thread_local std::string g_last_error;
@@ -521,6 +522,27 @@ int Engine::group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps,
                        hipStream_t s, void** raw_out) {
   const int C = x.C + (x1 ? x1->C : 0);
   T2P_REQUIRE(C == n.C, "GroupNorm channel mismatch");
+  T2P_REQUIRE(!x.lowp || (x.cstats && !x1), "a 16-bit activation needs fused statistics and a single source");
+  {
+    // small maps (<= 64 pixels): statistics + apply in one launch instead of two or three latency-bound ones
+    GroupNormApplyArgs g;
+    g.x0 = (const float*)x.p; g.x1 = x1 ? (const float*)x1->p : nullptr; g.C0 = x.C; g.C1 = x1 ? x1->C : 0;
+    g.B = B; g.H = x.H; g.W = x.W; g.G = n.G; g.gamma = n.gamma; g.beta = n.beta; g.silu = silu; g.down = down;
+    g.dtype = dtype(); g.x0_lowp = x.lowp; g.eps = eps;
+    if (g_gn_small && gn_small_eligible(g)) {
+      const size_t bytes = (size_t)B * x.H * x.W * C * dtype_size(dtype());
+      POOL_GET(o, void*, bytes);
+      g.out = o;
+      if (raw_out) {
+        *raw_out = pool_.get(bytes);
+        if (!*raw_out) return T2P_ERR_HIP;
+        g.raw_out = *raw_out;
+      }
+      T2P_TRY(launch_gn_small(g, s));
+      *out = o;
+      return T2P_OK;
+    }
+  }
   GroupNormArgs a;
   a.x0 = x.p; a.x1 = x1 ? x1->p : nullptr; a.C0 = x.C; a.C1 = x1 ? x1->C : 0;
   a.B = B; a.HW = x.H * x.W; a.G = n.G; a.eps = eps;
@@ -583,7 +605,10 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     // h1 is read once more, by GroupNorm_1 only: when its statistics come out of this epilogue
     // (computed from the fp32 values) the tensor itself is stored in the compute dtype
     T2P_TRY(attach_ws(p));
-    if (g_lowp_h1 && dt != DT_F32 && g_fuse_gn_stats && gemm_fuses_col_stats(p) && (Ho * Wo) % 64 == 0) {
+    // (maps of <= 64 pixels go through the single-launch GroupNorm, which takes its own statistics:
+    // h1 stays fp32 there so that they are still taken from unrounded values)
+    if (g_lowp_h1 && dt != DT_F32 && g_fuse_gn_stats && gemm_fuses_col_stats(p) && (Ho * Wo) % 64 == 0 &&
+        !(g_gn_small && Ho * Wo <= 64)) {
       p.c_f32 = 0;
       h1_lowp = gemm_fuses_col_stats_lowp(p);
       if (!h1_lowp) p.c_f32 = 1;

@@ -281,6 +281,97 @@ int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s) {
   return T2P_OK;
 }
 
+// ================================== GroupNorm of a small map, one launch ==========================
+// At the 4x4 / 8x8 levels a GroupNorm is three launch-latency-bound kernels (statistics, finalize,
+// apply: ~4.5 us each for a few KiB of data).  Here one 256-thread block owns up to 1024 channels of
+// one sample: pass 1 accumulates per-thread sums of its 4 channels over its pixels, the threads of a
+// group are folded in a fixed order through LDS (double, like gn_finalize), pass 2 re-reads the
+// (L2-resident) map and writes the normalised / activated result.  Same thread -> (channel, pixel)
+// mapping as gn_apply_kernel.
+template <typename TO, typename TI>
+__global__ __launch_bounds__(256) void gn_small_kernel(GroupNormApplyArgs a) {
+  __shared__ float part[256][8];
+  const int C = a.C0 + a.C1, HW = a.H * a.W;
+  const int b = blockIdx.y, c_lo = blockIdx.x * 1024;
+  const int nvec = min(C - c_lo, 1024) >> 2;
+  const int ppi = 256 / nvec;
+  const int tid = threadIdx.x;
+  const bool active = tid < ppi * nvec;
+  const int v = active ? tid % nvec : 0, po = active ? tid / nvec : 0;
+  const int c = c_lo + v * 4;
+  const int cpg = C / a.G;
+  const TI* src; int ld, cc;
+  if (c < a.C0) { src = (const TI*)a.x0; ld = a.C0; cc = c; } else { src = (const TI*)a.x1; ld = a.C1; cc = c - a.C0; }
+  src += (long)b * HW * ld + cc;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+  if (active)
+    for (int p = po; p < HW; p += ppi) {
+      const float4 t = load4<TI>(src + (long)p * ld);
+      s0 += t.x; s1 += t.y; s2 += t.z; s3 += t.w;
+      q0 += t.x * t.x; q1 += t.y * t.y; q2 += t.z * t.z; q3 += t.w * t.w;
+    }
+  part[tid][0] = s0; part[tid][1] = s1; part[tid][2] = s2; part[tid][3] = s3;
+  part[tid][4] = q0; part[tid][5] = q1; part[tid][6] = q2; part[tid][7] = q3;
+  __syncthreads();
+  if (!active) return;
+  // the group of this thread's 4 channels: channel vectors [v_lo, v_lo + cpg / 4) of every pixel lane
+  const int v_lo = ((c / cpg) * cpg - c_lo) >> 2, nv = cpg >> 2;
+  double s = 0, q = 0;
+  for (int l = 0; l < ppi; ++l)
+    for (int k = 0; k < nv; ++k) {
+      const float* e = part[l * nvec + v_lo + k];
+      s += (double)e[0] + (double)e[1] + (double)e[2] + (double)e[3];
+      q += (double)e[4] + (double)e[5] + (double)e[6] + (double)e[7];
+    }
+  const double n = (double)HW * cpg;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0) var = 0;
+  const float fmean = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  const float4 ga = *(const float4*)(a.gamma + c), be = *(const float4*)(a.beta + c);
+  const float sc0 = rstd * ga.x, sc1 = rstd * ga.y, sc2 = rstd * ga.z, sc3 = rstd * ga.w;
+  const float sh0 = be.x - fmean * sc0, sh1 = be.y - fmean * sc1, sh2 = be.z - fmean * sc2, sh3 = be.w - fmean * sc3;
+  TO* out = (TO*)a.out + (long)b * HW * C + c;
+  TO* raw = a.raw_out ? (TO*)a.raw_out + (long)b * HW * C + c : nullptr;
+  for (int p = po; p < HW; p += ppi) {
+    const float4 t = load4<TI>(src + (long)p * ld);
+    if (raw) store4<TO>(raw + (long)p * C, t.x, t.y, t.z, t.w);
+    float y0 = t.x * sc0 + sh0, y1 = t.y * sc1 + sh1, y2 = t.z * sc2 + sh2, y3 = t.w * sc3 + sh3;
+    if (a.silu) { y0 = silu_fast(y0); y1 = silu_fast(y1); y2 = silu_fast(y2); y3 = silu_fast(y3); }
+    store4<TO>(out + (long)p * C, y0, y1, y2, y3);
+  }
+}
+
+bool gn_small_eligible(const GroupNormApplyArgs& a) {
+  const int C = a.C0 + a.C1;
+  if (a.down || a.G <= 0 || C % a.G != 0 || a.H * a.W > 64) return false;
+  const int cpg = C / a.G;
+  if (cpg % 4 != 0 || a.C0 % 4 != 0 || a.C1 % 4 != 0) return false;
+  return C <= 1024 || 1024 % cpg == 0;               // a block's 1024 channels hold whole groups
+}
+
+int launch_gn_small(const GroupNormApplyArgs& a, hipStream_t s) {
+  const int C = a.C0 + a.C1;
+  T2P_REQUIRE(a.x0 && a.gamma && a.beta && a.out, "null pointer");
+  T2P_REQUIRE(gn_small_eligible(a), "gn_small: not eligible");
+  T2P_REQUIRE(!a.x0_lowp || (a.C1 == 0 && a.dtype != DT_F32), "16-bit GroupNorm input: single source, 16-bit dtype");
+  dim3 grid((C + 1023) / 1024, a.B);
+  switch (a.dtype) {
+    case DT_F32: hipLaunchKernelGGL((gn_small_kernel<float, float>), grid, dim3(256), 0, s, a); break;
+    case DT_BF16:
+      if (a.x0_lowp) hipLaunchKernelGGL((gn_small_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gn_small_kernel<bf16_t, float>), grid, dim3(256), 0, s, a);
+      break;
+    case DT_F16:
+      if (a.x0_lowp) hipLaunchKernelGGL((gn_small_kernel<f16_t, f16_t>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gn_small_kernel<f16_t, float>), grid, dim3(256), 0, s, a);
+      break;
+    default: set_last_error("gn_small: bad dtype"); return T2P_ERR_INVALID;
+  }
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
 // ================================== LayerNorm ====================================================
 // one wavefront per row; three passes over an L1/L2-resident row (C <= a few thousand).
 template <typename TO>

@@ -35,8 +35,12 @@ struct GroupNormApplyArgs {
   int x0_lowp = 0;                     // x0 is stored in `dtype` (16-bit) instead of fp32 (single source only)
   void* raw_out = nullptr;             // optional: un-normalised x (concat of both sources) in `dtype`,
                                        // same resolution as the input (not with `down`)
+  float eps = 0.f;                     // launch_gn_small only
 };
 int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s);
+// statistics + normalisation (+SiLU, + raw copy) of a small map in ONE launch (no `stats` input, no `down`)
+bool gn_small_eligible(const GroupNormApplyArgs& a);
+int launch_gn_small(const GroupNormApplyArgs& a, hipStream_t s);
 
 // ---- LayerNorm over the last axis (attention.py:203-205), eps 1e-5 ---------------------------
 int launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int dtype,
