@@ -199,9 +199,9 @@ def main():
         o = (C.c_double * 9)()
         check(lib.t2p_profile_end(o))
         conv_ms, conv_fl, conv_n, g_ms, g_fl, g_n, c1_ms, c1_fl, c1_n = list(o)
-        dom, dom_name = (C.c_double * 3)(), C.create_string_buffer(256)
+        dom, dom_name = (C.c_double * 4)(), C.create_string_buffer(256)
         check(lib.t2p_profile_dominant(dom, dom_name, 256))
-        dom_ms, dom_fl, dom_n = list(dom)
+        dom_ms, dom_fl, dom_n, dom_bytes = list(dom)
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         if conv_n == 0:            # fp32 mode: every convolution runs on the register-staged exact-f32 kernel
             conv_ms, conv_fl, conv_n, c1_ms, c1_fl, c1_n = c1_ms, c1_fl, c1_n, 0.0, 0.0, 0.0
@@ -229,6 +229,7 @@ def main():
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
             "launches_per_step": conv_n / nprof, "avg_launch_ms": conv_ms / max(conv_n, 1),
             "algorithmic_gflop_per_launch": conv_fl / max(conv_n, 1) / 1e9,
+            "algorithmic_bytes_per_launch": (dom_bytes / dom_n) if dom_n > 0 else None,
             "share_of_step_ms": conv_ms / nprof,
             "all_conv3x3_launches": all_conv,
             "other_gemm": {"achieved": g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0, "launches_per_step": g_n / nprof,

@@ -183,9 +183,10 @@ int t2p_profile_begin(void);
 int t2p_debug_set(int key, int value);
 int t2p_profile_end(double* out9);
 /* after t2p_profile_end: the 3x3-convolution kernel instantiation with the largest total time in that region --
- * out3 = {ms (main kernel only), flops, launches}, name = the kernel name as rocprofv3 reports it (no argument list),
- * so that bench.py's live average launch duration can be checked against profiles/<round>_kernel_stats.csv */
-int t2p_profile_dominant(double* out3, char* name, int name_len);
+ * out4 = {ms (main kernel only), flops, launches, algorithmic bytes (inputs, weights, residual and output once each)},
+ * name = the kernel name as rocprofv3 reports it (no argument list), so that bench.py's live average launch duration
+ * can be checked against profiles/<round>_kernel_stats.csv and the PMC traffic against the algorithmic bytes */
+int t2p_profile_dominant(double* out4, char* name, int name_len);
 
 #ifdef __cplusplus
 }

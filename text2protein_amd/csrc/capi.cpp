@@ -384,11 +384,11 @@ int t2p_profile_end(double* out9) {
   API_END
 }
 
-int t2p_profile_dominant(double* out3, char* name, int name_len) {
+int t2p_profile_dominant(double* out4, char* name, int name_len) {
   API_BEGIN
-  T2P_REQUIRE(out3 && name && name_len > 0, "null argument");
+  T2P_REQUIRE(out4 && name && name_len > 0, "null argument");
   const char* n = nullptr;
-  T2P_TRY(profile_dominant(out3, &n));
+  T2P_TRY(profile_dominant(out4, &n));
   std::snprintf(name, (size_t)name_len, "%s", n ? n : "");
   return T2P_OK;
   API_END

@@ -950,12 +950,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
 }
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream -----------
-struct ProfRec { hipEvent_t a, b; double flops; int kind; const char* name; };
+struct ProfRec { hipEvent_t a, b; double flops; int kind; const char* name; double bytes; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 // the 3x3-convolution instantiation with the largest total time of the last profiled region
 static std::string g_dom_name;
-static double g_dom[3] = {0, 0, 0};
+static double g_dom[4] = {0, 0, 0, 0};
 
 void profile_begin() {
   for (ProfRec& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -968,7 +968,7 @@ void profile_begin() {
 int profile_end(double out[3][3]) {
   g_prof_on = false;
   for (int k = 0; k < 3; ++k) out[k][0] = out[k][1] = out[k][2] = 0;
-  std::map<std::string, std::array<double, 3>> per;
+  std::map<std::string, std::array<double, 4>> per;
   for (ProfRec& r : g_prof) {
     T2P_HIP_CHECK(hipEventSynchronize(r.b));
     float ms = 0.f;
@@ -976,22 +976,23 @@ int profile_end(double out[3][3]) {
     out[r.kind][0] += ms; out[r.kind][1] += r.flops; out[r.kind][2] += 1;
     if (r.kind == 0 && r.name) {
       auto& e = per[r.name];
-      e[0] += ms; e[1] += r.flops; e[2] += 1;
+      e[0] += ms; e[1] += r.flops; e[2] += 1; e[3] += r.bytes;
     }
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
   g_prof.clear();
   g_dom_name.clear();
-  g_dom[0] = g_dom[1] = g_dom[2] = 0;
+  g_dom[0] = g_dom[1] = g_dom[2] = g_dom[3] = 0;
   for (auto& kv : per)
-    if (kv.second[0] > g_dom[0]) { g_dom_name = kv.first; g_dom[0] = kv.second[0]; g_dom[1] = kv.second[1]; g_dom[2] = kv.second[2]; }
+    if (kv.second[0] > g_dom[0]) { g_dom_name = kv.first; for (int i = 0; i < 4; ++i) g_dom[i] = kv.second[i]; }
   return T2P_OK;
 }
 
-// {milliseconds, flops, launches} and the kernel name (as rocprofv3 prints it, without the argument list) of the
-// dominant 3x3-convolution instantiation of the region closed by the last profile_end
-int profile_dominant(double out[3], const char** name) {
-  out[0] = g_dom[0]; out[1] = g_dom[1]; out[2] = g_dom[2];
+// {milliseconds, flops, launches, algorithmic bytes} and the kernel name (as rocprofv3 prints it, without the
+// argument list) of the dominant 3x3-convolution instantiation of the region closed by the last profile_end.
+// Algorithmic bytes of a launch: every input element, weight, residual element once + the output once.
+int profile_dominant(double out[4], const char** name) {
+  out[0] = g_dom[0]; out[1] = g_dom[1]; out[2] = g_dom[2]; out[3] = g_dom[3];
   *name = g_dom_name.c_str();
   return T2P_OK;
 }
@@ -1013,6 +1014,7 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
     rec.flops = 2.0 * p.M * p.N * (double)p.taps * (p.C0 + p.C1) * p.nz0 * p.nz1;
     rec.kind = p.taps == 9 ? 2 : 1;
     rec.name = nullptr;
+    rec.bytes = 0;
     T2P_HIP_CHECK(hipEventRecord(rec.a, stream));
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
@@ -1264,6 +1266,12 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
                                      ", " + std::to_string(MODE) + ", " + std::to_string(NST) + ", " + std::to_string(NSTB) + ", " +
                                      (MF16 ? "true" : "false") + ">";
     rec.name = kname.c_str();
+    {
+      const double Ct = p.C0 + p.C1, z = (double)p.nz0 * p.nz1;
+      const double a_rows = p.a_up ? p.M / 4.0 : p.M;                    // up-sampling convs gather from the half-resolution map
+      rec.bytes = z * (a_rows * Ct * 2 + (double)p.N * p.taps * Ct * 2 + (double)p.M * (p.geglu ? p.N / 2 : p.N) * (p.c_f32 ? 4 : 2) +
+                       (p.R ? (double)p.M * p.N * 4 / (p.r_up ? 4 : 1) : 0.0) + (p.bias_bn ? (double)(p.M / p.rows_per_batch) * p.N * 4 : 0.0));
+    }
     T2P_HIP_CHECK(hipEventRecord(rec.a, stream));
   }
   hipLaunchKernelGGL(kern, grid, dim3(threads), smem, stream, p, tiles_m, tiles_n, g_dbg);

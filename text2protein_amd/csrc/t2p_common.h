@@ -144,6 +144,6 @@ extern bool g_fuse_gn_stats;   // engine: GroupNorm statistics from the producin
 extern bool g_raw_copies;   // engine: feed 1x1 shortcut / proj_out GEMMs with compute-dtype copies
 void profile_begin();
 int profile_end(double out[3][3]);
-int profile_dominant(double out[3], const char** name);
+int profile_dominant(double out[4], const char** name);
 
 }  // namespace t2p
