@@ -127,6 +127,10 @@ int t2p_sampler_run(t2p_sampler* s, float* x, float* out, int prior_given, int n
 int t2p_op_gemm(int dtype, const void* A, int a_f32, const void* Bw, void* C, int c_f32, int M, int N, int K,
                 int64_t lda, int64_t ldb, int64_t ldc, const float* bias_n, const float* residual, float alpha,
                 void* stream);
+/* the same with the residual stored in the compute dtype (f16 / bf16) instead of fp32: the form the engine uses for
+ * the residual stream between blocks in f16 mode */
+int t2p_op_gemm_r16(int dtype, const void* A, int a_f32, const void* Bw, void* C, int c_f32, int M, int N, int K, int64_t lda,
+                    int64_t ldb, int64_t ldc, const float* bias_n, const void* residual16, float alpha, void* stream);
 /* x: NHWC in the given layout; w: [Cout][3][3][Cin] compute dtype; out fp32 NHWC */
 int t2p_op_conv3x3(int dtype, const void* x, int a_f32, const void* w, const float* bias, float* out, int batch,
                    int H, int W, int Cin, int Cout, int upsample, void* stream);

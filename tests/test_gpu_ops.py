@@ -339,3 +339,30 @@ def test_conv_midsize_splitk_plan(lib):
     finally:
         lib.t2p_debug_set(10, 0)
         lib.t2p_debug_set(12, 1)
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("M,N,K,ws", [(4096, 512, 1024, 0),     # LDS-DMA kernel, lean epilogue
+                                      (1000, 130, 192, 0),      # ragged: generic epilogue
+                                      (300, 72, 40, 0),         # register-staged kernel
+                                      (512, 256, 2304, 64)])    # split-K: vectorised second pass
+def test_gemm_16bit_residual(lib, dt, M, N, K, ws):
+    """t2p_op_gemm_r16: the residual operand stored in the compute dtype (the f16-mode residual stream)."""
+    td = TDT[dt]
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).to(td)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(td)
+    bias = torch.randn(N, generator=g)
+    res = (torch.randn(M, N, generator=g) * 3).to(td)
+    ref = (a.double() @ w.double().T + bias.double() + res.double()) * 0.5
+    try:
+        if ws:
+            check(lib, lib.t2p_debug_set(10, ws))
+        for c_f32 in (1, 0):
+            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if c_f32 else td)
+            check(lib, lib.t2p_op_gemm_r16(dt, P(dev(a)), 0, P(dev(w)), P(out), c_f32, M, N, K, K, K, N, P(dev(bias)), P(dev(res)), 0.5, None))
+            torch.cuda.synchronize()
+            tol = 3e-6 if c_f32 else 2 * TOL[dt]
+            assert rel_l2(out.float().cpu(), ref) < tol, (dt, M, N, K, c_f32)
+    finally:
+        lib.t2p_debug_set(10, 0)

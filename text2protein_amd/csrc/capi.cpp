@@ -167,6 +167,20 @@ int t2p_op_gemm(int dtype, const void* A, int a_f32, const void* Bw, void* C, in
 static void* g_op_ws = nullptr;
 static size_t g_op_ws_bytes = 0;
 
+int t2p_op_gemm_r16(int dtype, const void* A, int a_f32, const void* Bw, void* C, int c_f32, int M, int N, int K, int64_t lda,
+                    int64_t ldb, int64_t ldc, const float* bias_n, const void* residual16, float alpha, void* stream) {
+  API_BEGIN
+  GemmParams p;
+  p.dtype = dtype; p.A0 = A; p.a_f32 = a_f32; p.C0 = K; p.lda0 = lda; p.Bw = Bw; p.ldb = ldb; p.M = M; p.N = N;
+  p.bias_n = bias_n; p.R = (const float*)residual16; p.r_lowp = 1; p.ldr = ldc; p.alpha = alpha; p.C = C; p.c_f32 = c_f32; p.ldc = ldc;
+  if (g_op_ws_bytes) {   // development switch (t2p_debug_set key 10): lets the op entry take the split-K path
+    if (!g_op_ws) T2P_HIP_CHECK(hipMalloc(&g_op_ws, g_op_ws_bytes));
+    p.ws = g_op_ws; p.ws_bytes = g_op_ws_bytes;
+  }
+  return launch_gemm(p, (hipStream_t)stream);
+  API_END
+}
+
 int t2p_op_conv3x3(int dtype, const void* x, int a_f32, const void* w, const float* bias, float* out, int batch, int H,
                    int W, int Cin, int Cout, int upsample, void* stream) {
   API_BEGIN

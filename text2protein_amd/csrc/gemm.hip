@@ -107,6 +107,29 @@ template <> struct Mma<f16_t> {
   }
 };
 
+typedef float f32x4_res_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_res_t __attribute__((ext_vector_type(2)));
+// residual operand: fp32, or the compute dtype when GemmParams::r_lowp (element index, not bytes)
+template <typename TC> __device__ inline float res_load1(const float* R, long idx, int lowp) {
+  if constexpr (sizeof(TC) == 2) { if (lowp) return to_f32(((const TC*)R)[idx]); }
+  return R[idx];
+}
+template <typename TC> __device__ inline f32x4_res_t unpack4(u32x2_res_t u) {     // four 16-bit values -> fp32
+  TC e[4];
+  e[0] = __builtin_bit_cast(TC, (uint16_t)u.x); e[1] = __builtin_bit_cast(TC, (uint16_t)(u.x >> 16));
+  e[2] = __builtin_bit_cast(TC, (uint16_t)u.y); e[3] = __builtin_bit_cast(TC, (uint16_t)(u.y >> 16));
+  return (f32x4_res_t){to_f32(e[0]), to_f32(e[1]), to_f32(e[2]), to_f32(e[3])};
+}
+template <typename TC> __device__ inline float4 res_load4(const float* R, long idx, int lowp) {
+  if constexpr (sizeof(TC) == 2) {
+    if (lowp) {
+      const f32x4_res_t v = unpack4<TC>(*(const u32x2_res_t*)((const TC*)R + idx));
+      return make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  return *(const float4*)(R + idx);
+}
+
 template <typename TC, bool AF32, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int VEC = VecInfo<TC>::VEC;
@@ -237,7 +260,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
   // ---- epilogue ---------------------------------------------------------------------------
   const long coff = (long)z0 * p.sC_z0 + (long)z1 * p.sC_z1;
-  const float* R = p.R ? p.R + (long)z0 * p.sR_z0 + (long)z1 * p.sR_z1 : nullptr;
+  const float* R = p.R ? (p.r_lowp ? (const float*)((const uint16_t*)p.R + (long)z0 * p.sR_z0 + (long)z1 * p.sR_z1)
+                                   : p.R + (long)z0 * p.sR_z0 + (long)z1 * p.sR_z1) : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -259,7 +283,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         float val = acc[i][j][v] + bm;
         if (p.bias_n) val += p.bias_n[col];
         if (p.bias_bn) val += p.bias_bn[(long)bidx * p.ld_bn + col];
-        if (R) val += R[rrow * p.ldr + col];
+        if (R) val += res_load1<TC>(R, rrow * p.ldr + col, p.r_lowp);
         val *= p.alpha;
         if (p.c_nchw) {
           const int pix = row - bidx * p.rows_per_batch;
@@ -351,7 +375,7 @@ template <int I> __device__ inline void lds_read_b128_2k(u32x4_t& dst, unsigned 
 // loop is branch-free: 8 LDS reads and (HAS_R) 8 residual loads at a time are in flight before the
 // first use.  OUT: 0 fp32, 1 compute dtype, 2 GEGLU (interleaved value / gate columns ->
 // compute dtype), 3 raw split-K partial.  Every variant issues exactly 16 stores.
-template <typename TC, int OUT, bool HAS_R, bool STATS>
+template <typename TC, int OUT, bool HAS_R, bool STATS, bool RL = false>
 __device__ __forceinline__ void lean_slab(const float* sp, const __amdgpu_buffer_rsrc_t rC, const __amdgpu_buffer_rsrc_t rR,
                                           unsigned voc, const unsigned stc, unsigned vor, const unsigned str,
                                           const float4 bn0, const float4 bn1, const int row_first, const int b_edge,
@@ -381,7 +405,8 @@ __device__ __forceinline__ void lean_slab(const float* sp, const __amdgpu_buffer
     if constexpr (HAS_R) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        rv[i] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rR, vor, 0, 0));
+        if constexpr (RL) rv[i] = unpack4<TC>(__builtin_amdgcn_raw_buffer_load_b64(rR, vor, 0, 0));   // 16-bit residual
+        else rv[i] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rR, vor, 0, 0));
         vor += str;
       }
     }
@@ -755,7 +780,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   __builtin_amdgcn_s_barrier();                       // every wave is done reading the last stage
   float* stg = (float*)(smem + wave * 16384);         // [64 rows][64 cols] fp32
   const long coff = (long)z0 * p.sC_z0 + (long)z1 * p.sC_z1;
-  const float* R = p.R ? p.R + (long)z0 * p.sR_z0 + (long)z1 * p.sR_z1 : nullptr;
+  const float* R = p.R ? (p.r_lowp ? (const float*)((const uint16_t*)p.R + (long)z0 * p.sR_z0 + (long)z1 * p.sR_z1)
+                                   : p.R + (long)z0 * p.sR_z0 + (long)z1 * p.sR_z1) : nullptr;
   const bool need_b = p.bias_bn || p.r_up;
   const int rpb = p.rows_per_batch;
   const int b_first = need_b ? m0 / rpb : 0;          // a BM-row tile spans at most two samples when rpb >= BM
@@ -769,7 +795,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   // (row bias, up-sampled residual, samples shorter than a tile, unaligned strides, >= 2 GiB operands).
   const int c_cols = p.geglu ? p.N / 2 : p.N;
   const long c_bytes = ws ? (long)p.M * p.N * 4 : ((long)(p.M - 1) * p.ldc + c_cols) * (p.c_f32 ? 4 : 2);
-  const long r_bytes = R ? ((long)(p.M - 1) * p.ldr + p.N) * 4 : 0;
+  const long r_bytes = R ? ((long)(p.M - 1) * p.ldr + p.N) * (p.r_lowp ? 2 : 4) : 0;
   const bool lean = !(dbg & 512) && (p.N & 3) == 0 && c_bytes < (1L << 31) && r_bytes < (1L << 31) &&
                     (ws != nullptr || (!p.bias_m && !p.r_up && (!need_b || rpb >= BM) && (p.geglu ? p.ldc % 2 == 0 : p.ldc % 4 == 0) &&
                                        (!R || p.ldr % 4 == 0) && (!p.bias_bn || p.ld_bn % 4 == 0)));
@@ -814,8 +840,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
         const unsigned ldc_e = ws ? (unsigned)p.N : (unsigned)p.ldc;
         const unsigned voc = (col_ok && !(dbg & 1024)) ? ((unsigned)(row0 + rq) * ldc_e + (unsigned)(p.geglu ? col >> 1 : col)) * esz : DMA_OOB;
         const unsigned stc = 4u * ldc_e * esz;
-        const unsigned vor = col_ok ? ((unsigned)(row0 + rq) * (unsigned)p.ldr + (unsigned)col) * 4u : DMA_OOB;
-        const unsigned str = 16u * (unsigned)p.ldr;
+        const unsigned rsz = p.r_lowp ? 2u : 4u;
+        const unsigned vor = col_ok ? ((unsigned)(row0 + rq) * (unsigned)p.ldr + (unsigned)col) * rsz : DMA_OOB;
+        const unsigned str = 4u * rsz * (unsigned)p.ldr;
         float4 bn0 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!ws && p.bias_n && col_ok) bn0 = *(const float4*)(p.bias_n + col);
         float4 bn1 = bn0;
@@ -829,7 +856,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
         }
         const int edge = two_b ? b_edge : 0x7fffffff;
         float* sd = (p.col_stats && lane < 16 && col_ok && row0 < p.M) ? p.col_stats + ((long)(row0 >> 6) * p.N + col) * 2 : nullptr;
-#define T2P_LEAN(OUT, HR, ST) lean_slab<TC, OUT, HR, ST>(sp, rC, rR, voc, stc, vor, str, bn0, bn1, row0 + rq, edge, p.alpha, sd)
+#define T2P_LEAN(OUT, HR, ST)                                                                                             \
+  do {                                                                                                                   \
+    if (HR && p.r_lowp) lean_slab<TC, OUT, HR, ST, HR>(sp, rC, rR, voc, stc, vor, str, bn0, bn1, row0 + rq, edge, p.alpha, sd); \
+    else lean_slab<TC, OUT, HR, ST, false>(sp, rC, rR, voc, stc, vor, str, bn0, bn1, row0 + rq, edge, p.alpha, sd);      \
+  } while (0)
         if (ws) T2P_LEAN(3, false, false);
         else if (p.geglu) T2P_LEAN(2, false, false);
         else if (p.c_f32) {
@@ -894,7 +925,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
             a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
           }
           if (R) {
-            const float4 t = *(const float4*)(R + rrow * p.ldr + col);
+            const float4 t = res_load4<TC>(R, rrow * p.ldr + col, p.r_lowp);
             a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
           }
           if (p.geglu) {
@@ -925,7 +956,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
             if (col + k >= p.N) break;
             float val = vals[k];
             if (p.bias_bn) val += p.bias_bn[(long)bidx * p.ld_bn + col + k];
-            if (R) val += R[rrow * p.ldr + col + k];
+            if (R) val += res_load1<TC>(R, rrow * p.ldr + col + k, p.r_lowp);
             val *= p.alpha;
             if (p.c_f32) ((float*)p.C)[coff + (long)row * p.ldc + col + k] = val;
             else ((TC*)p.C)[coff + (long)row * p.ldc + col + k] = from_f32<TC>(val);
@@ -1073,7 +1104,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     if (p.bias_m) val += p.bias_m[row];
     if (p.bias_n) val += p.bias_n[col];
     if (p.bias_bn) val += p.bias_bn[(long)bidx * p.ld_bn + col];
-    if (p.R) val += p.R[rrow * p.ldr + col];
+    if (p.R) val += res_load1<TC>(p.R, rrow * p.ldr + col, p.r_lowp);
     val *= p.alpha;
     if (p.c_f32) ((float*)p.C)[(long)row * p.ldc + col] = val;
     else ((TC*)p.C)[(long)row * p.ldc + col] = from_f32<TC>(val);
@@ -1133,7 +1164,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmParams
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     if (p.R) {
-      const float4 b = *(const float4*)(p.R + rrow * p.ldr + col);
+      const float4 b = res_load4<TC>(p.R, rrow * p.ldr + col, p.r_lowp);
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     a.x *= p.alpha; a.y *= p.alpha; a.z *= p.alpha; a.w *= p.alpha;
@@ -1270,7 +1301,7 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
       const double Ct = p.C0 + p.C1, z = (double)p.nz0 * p.nz1;
       const double a_rows = p.a_up ? p.M / 4.0 : p.M;                    // up-sampling convs gather from the half-resolution map
       rec.bytes = z * (a_rows * Ct * 2 + (double)p.N * p.taps * Ct * 2 + (double)p.M * (p.geglu ? p.N / 2 : p.N) * (p.c_f32 ? 4 : 2) +
-                       (p.R ? (double)p.M * p.N * 4 / (p.r_up ? 4 : 1) : 0.0) + (p.bias_bn ? (double)(p.M / p.rows_per_batch) * p.N * 4 : 0.0));
+                       (p.R ? (double)p.M * p.N * (p.r_lowp ? 2 : 4) / (p.r_up ? 4 : 1) : 0.0) + (p.bias_bn ? (double)(p.M / p.rows_per_batch) * p.N * 4 : 0.0));
     }
     T2P_HIP_CHECK(hipEventRecord(rec.a, stream));
   }
@@ -1330,6 +1361,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
   T2P_REQUIRE(p.M > 0 && p.N > 0 && Ctot > 0, "empty problem");
   T2P_REQUIRE(p.taps == 1 || p.taps == 9, "taps must be 1 or 9");
   T2P_REQUIRE(p.dtype != DT_F32 || p.a_f32, "fp32 compute takes fp32 sources");
+  T2P_REQUIRE(!p.r_lowp || (p.R && p.dtype != DT_F32), "a 16-bit residual needs a 16-bit compute dtype");
   T2P_REQUIRE(p.lda0 % vec == 0 && p.ldb % vec == 0, "row strides must be multiples of the 16-byte vector");
   T2P_REQUIRE(p.lda0 >= ((p.C0 + vec - 1) / vec) * vec, "lda0 too small");
   T2P_REQUIRE(p.ldb >= (long)(p.taps - 1) * Ctot + ((Ctot + vec - 1) / vec) * vec, "ldb too small");

@@ -109,7 +109,8 @@ struct GemmParams {
   const float* bias_bn = nullptr;  // [batch][ld_bn]
   int rows_per_batch = 1;
   long ld_bn = 0;
-  const float* R = nullptr;  // fp32 residual
+  const float* R = nullptr;  // residual: fp32, or compute dtype (16-bit) when r_lowp
+  int r_lowp = 0;
   long ldr = 0;
   int r_up = 0;              // residual lives at half resolution (uses H, W, rows_per_batch = H*W)
   float alpha = 1.f;
