@@ -176,3 +176,17 @@ def test_checkpoint_roundtrip_layout(tmp_path):
     ref = synth.synth_state_dict(cfg, 2)
     assert list(sd) == list(ref) and all(torch.equal(sd[k], ref[k]) for k in ref)
     assert checkpoint.strip_module_prefix(st["model"]).keys() >= ref.keys()
+
+
+def test_build_flags_scratch_spills():
+    """The build fails when an LDS-DMA GEMM kernel uses scratch memory (a rolled accumulator loop is
+    correct but several times slower): the parser behind that check."""
+    from text2protein_amd.build import scratch_users
+    remarks = """gemm.hip:1:1: remark: Function Name: _ZN3t2p15gemm_dma_kernelIaEEv [-Rpass-analysis=kernel-resource-usage]
+gemm.hip:1:1: remark:     VGPRs: 256 [-Rpass-analysis=kernel-resource-usage]
+gemm.hip:1:1: remark:     ScratchSize [bytes/lane]: 544 [-Rpass-analysis=kernel-resource-usage]
+gemm.hip:2:1: remark: Function Name: _ZN3t2p15gemm_dma_kernelIbEEv [-Rpass-analysis=kernel-resource-usage]
+gemm.hip:2:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]
+gemm.hip:3:1: remark: Function Name: _ZN3t2p11gemm_kernelIfEEv [-Rpass-analysis=kernel-resource-usage]
+gemm.hip:3:1: remark:     ScratchSize [bytes/lane]: 16 [-Rpass-analysis=kernel-resource-usage]"""
+    assert scratch_users(remarks) == [("_ZN3t2p15gemm_dma_kernelIaEEv", 544)]

@@ -3,6 +3,7 @@ so that it travels to the GPU box with the repository snapshot."""
 from __future__ import annotations
 
 import os
+import re
 import subprocess
 import sys
 
@@ -27,6 +28,23 @@ def needs_build() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def scratch_users(remarks: str, kernel_prefix: str = "gemm_dma_kernel"):
+    """Kernels whose -Rpass-analysis=kernel-resource-usage remarks report scratch (private memory).
+
+    The LDS-DMA GEMM keeps 128 accumulator registers per lane; if a loop over them is left rolled
+    (a `#pragma unroll` body that grew too large is skipped silently) they move to scratch and the
+    kernel runs several times slower while still producing correct results.  Caught here, on the CPU."""
+    bad, name = [], None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name and kernel_prefix in name and int(m.group(1)) > 0:
+            bad.append((name, int(m.group(1))))
+    return bad
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP/C++ source for gfx950 and link the shared library; returns its path."""
     if not force and not needs_build():
@@ -39,6 +57,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         cmd = [hipcc, *flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if src == "gemm.hip":
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -46,6 +66,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if src == "gemm.hip":
+            bad = scratch_users(out)
+            if bad:
+                raise RuntimeError("LDS-DMA GEMM kernels spill to scratch memory (accumulator loop left rolled?): "
+                                   + ", ".join(f"{n} {b} B/lane" for n, b in bad[:4]))
+            keep, skip = [], 0          # drop the remarks and the two source-context lines that follow each of them
+            for l in out.splitlines():
+                if "remark:" in l:
+                    skip = 2
+                elif skip and re.match(r"^\s*(\d+\s*)?\|", l):
+                    skip -= 1
+                else:
+                    skip = 0
+                    keep.append(l)
+            out = "\n".join(keep)
         if verbose and out.strip():
             print(out)
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]

@@ -15,6 +15,7 @@ bool g_fuse_gn_stats = true;
 bool g_fuse_geglu = true;
 bool g_lowp_h1 = true;
 bool g_gn_small = true;
+bool g_lowp_residual = true;
 bool g_raw_copies = true;
 bool g_flash_attention = true;
 static thread_local std::string g_last_error;
@@ -504,14 +505,14 @@ int Engine::gemm_stats(GemmParams& p, float** cstats, hipStream_t s) {
 }
 
 int Engine::linear(const void* a, bool a_is_f32, const DevLinear& w, long rows, void* c, bool c_f32,
-                   const float* residual, float alpha, hipStream_t s, bool use_bias, float** cstats) {
+                   const float* residual, float alpha, hipStream_t s, bool use_bias, float** cstats, bool r_lowp) {
   GemmParams p;
   p.dtype = dtype();
   p.A0 = a; p.a_f32 = a_is_f32 || p.dtype == DT_F32; p.C0 = w.K; p.lda0 = w.K;
   p.Bw = w.w; p.ldb = w.K;
   p.M = (int)rows; p.N = w.N;
   p.bias_n = use_bias ? w.b : nullptr;
-  p.R = residual; p.ldr = w.N;
+  p.R = residual; p.ldr = w.N; p.r_lowp = (residual && r_lowp) ? 1 : 0;
   p.alpha = alpha;
   p.C = c; p.c_f32 = c_f32; p.ldc = w.N;
   if (cstats) return gemm_stats(p, cstats, s);
@@ -522,7 +523,8 @@ int Engine::group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps,
                        hipStream_t s, void** raw_out) {
   const int C = x.C + (x1 ? x1->C : 0);
   T2P_REQUIRE(C == n.C, "GroupNorm channel mismatch");
-  T2P_REQUIRE(!x.lowp || (x.cstats && !x1), "a 16-bit activation needs fused statistics and a single source");
+  T2P_REQUIRE(!x1 || x1->lowp == x.lowp, "concatenated sources must share a storage type");
+  T2P_REQUIRE(!x.lowp || dtype() != DT_F32, "16-bit activations exist in the 16-bit modes only");
   {
     // small maps (<= 64 pixels): statistics + apply in one launch instead of two or three latency-bound ones
     GroupNormApplyArgs g;
@@ -556,13 +558,13 @@ int Engine::group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps,
     partial = (float*)pool_.get((size_t)B * nparts * n.G * 2 * 4);
     if (!partial) return T2P_ERR_HIP;
     a.partial = partial; a.stats = stats;
+    a.lowp_dtype = x.lowp ? dtype() : DT_F32;
     T2P_TRY(launch_gn_stats(a, s));
   }
   GroupNormApplyArgs g;
   g.x0 = a.x0; g.x1 = a.x1; g.C0 = a.C0; g.C1 = a.C1; g.B = B; g.H = x.H; g.W = x.W; g.G = n.G;
   g.stats = stats; g.gamma = n.gamma; g.beta = n.beta; g.silu = silu; g.down = down; g.dtype = dtype();
   g.x0_lowp = x.lowp;
-  T2P_REQUIRE(!x.lowp || (x.cstats && !x1), "a 16-bit activation needs fused statistics and a single source");
   const size_t opix = (size_t)B * (down ? x.H / 2 : x.H) * (down ? x.W / 2 : x.W);
   POOL_GET(o, void*, opix * C * dtype_size(dtype()));
   g.out = o;
@@ -590,7 +592,8 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
   // the 1x1 shortcut reads the raw block input: in 16-bit modes GroupNorm-apply (which reads it
   // anyway) also emits it in the compute dtype, so the shortcut GEMM takes the LDS-DMA kernel
   void* xraw = nullptr;
-  const bool want_raw = g_raw_copies && L.has_conv2 && !L.down && dt != DT_F32;
+  // (a 16-bit residual stream is already in the GEMM operand format: no raw copy)
+  const bool want_raw = g_raw_copies && L.has_conv2 && !L.down && dt != DT_F32 && !x.lowp;
   T2P_TRY(group_norm(x, skip, L.gn0, 1e-6f, 1, L.down, B, &a0, s, want_raw ? &xraw : nullptr));
   float* h1_stats = nullptr;
   bool h1_lowp = false;
@@ -633,14 +636,14 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     if (L.down) {
       pooled = pool_.get((size_t)rows_out * Cin * dtype_size(dt));
       if (!pooled) return T2P_ERR_HIP;
-      T2P_TRY(launch_pool2x2(x.p, pooled, dt, B, x.H, x.W, Cin, s));
+      T2P_TRY(launch_pool2x2(x.p, pooled, dt, B, x.H, x.W, Cin, s, x.lowp));
       p.A0 = pooled; p.C0 = Cin; p.lda0 = Cin;
       rrows = rows_out;
     } else {
       if (xraw) {
         p.A0 = xraw; p.C0 = Cin; p.lda0 = Cin;
       } else {
-        p.a_f32 = 1;
+        p.a_f32 = x.lowp ? 0 : 1;       // 16-bit stream: the LDS-DMA kernel reads both concat sources in place
         p.A0 = x.p; p.C0 = x.C; p.lda0 = x.C;
         if (skip) { p.A1 = skip->p; p.C1 = skip->C; p.lda1 = skip->C; }
       }
@@ -658,7 +661,8 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
   } else {
     T2P_REQUIRE(!skip && Cin == Cout, "identity shortcut needs equal channels");
   }
-  POOL_GET(o, float*, (size_t)rows_out * Cout * 4);
+  const bool olp = res_lowp();           // block output (the residual stream) in the compute dtype
+  POOL_GET(o, float*, (size_t)rows_out * Cout * (olp ? dtype_size(dt) : 4));
   float* o_stats = nullptr;
   {
     GemmParams p;
@@ -667,13 +671,14 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     p.Bw = L.conv1.w; p.ldb = L.conv1.K; p.M = (int)rows_out; p.N = Cout;
     p.bias_n = L.conv1.b; p.rows_per_batch = Ho * Wo;
     p.R = r; p.ldr = Cout; p.r_up = r_up;
+    p.r_lowp = (r == x.p && x.lowp) ? 1 : 0;          // identity shortcut: the block input itself; conv2 output is fp32
     p.alpha = cfg_.skip_rescale ? 0.70710678118654752440f : 1.f;
-    p.C = o; p.c_f32 = 1; p.ldc = Cout;
+    p.C = o; p.c_f32 = olp ? 0 : 1; p.ldc = Cout;
     T2P_TRY(gemm_stats(p, &o_stats, s));
   }
   pool_.put(a1);
   pool_.put(rbuf);
-  *out = Act{o, Cout, Ho, Wo, o_stats};
+  *out = Act{o, Cout, Ho, Wo, o_stats, olp};
   return T2P_OK;
 }
 
@@ -739,11 +744,12 @@ int Engine::attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   T2P_TRY(attention(qk, 2 * C, qk + (size_t)C * es, 2 * C, vt, npad, o, B, 1, n, n, C, 1.f / std::sqrt((float)C), s));
   pool_.put(qk);
   pool_.put(vt);
-  POOL_GET(y, float*, (size_t)rows * C * 4);
+  const bool olp = res_lowp();
+  POOL_GET(y, float*, (size_t)rows * C * (olp ? es : 4));
   float* y_stats = nullptr;
-  T2P_TRY(linear(o, false, L.out, rows, y, true, x.p, cfg_.skip_rescale ? 0.70710678118654752440f : 1.f, s, true, &y_stats));
+  T2P_TRY(linear(o, false, L.out, rows, y, !olp, x.p, cfg_.skip_rescale ? 0.70710678118654752440f : 1.f, s, true, &y_stats, x.lowp));
   pool_.put(o);
-  *out = Act{y, C, x.H, x.W, y_stats};
+  *out = Act{y, C, x.H, x.W, y_stats, olp};
   return T2P_OK;
 }
 
@@ -803,17 +809,18 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     pool_.put(g);
   }
   pool_.put(o);
-  POOL_GET(y, float*, (size_t)rows * C * 4);
+  const bool olp = res_lowp();
+  POOL_GET(y, float*, (size_t)rows * C * (olp ? es : 4));
   float* y_stats = nullptr;
   if (dt != DT_F32 && g_raw_copies) {
     T2P_TRY(launch_convert(t, ln, dt, rows * C, s));     // residual stream -> compute dtype (reuses the LN buffer)
-    T2P_TRY(linear(ln, false, L.proj_out, rows, y, true, x.p, 1.f, s, true, &y_stats));
+    T2P_TRY(linear(ln, false, L.proj_out, rows, y, !olp, x.p, 1.f, s, true, &y_stats, x.lowp));
   } else {
-    T2P_TRY(linear(t, true, L.proj_out, rows, y, true, x.p, 1.f, s, true, &y_stats));
+    T2P_TRY(linear(t, true, L.proj_out, rows, y, !olp, x.p, 1.f, s, true, &y_stats, x.lowp));
   }
   pool_.put(ln);
   pool_.put(t);
-  *out = Act{y, C, x.H, x.W, y_stats};
+  *out = Act{y, C, x.H, x.W, y_stats, olp};
   return T2P_OK;
 }
 
@@ -897,9 +904,10 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
     T2P_HIP_CHECK(hipMemcpyAsync(scale, ones.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
     T2P_HIP_CHECK(hipStreamSynchronize(s));
   }
-  POOL_GET(h0, float*, (size_t)B * HW * nf_ * 4);
+  const bool hlp = res_lowp() && (Cx == 5 || Cx == 8) && pre_conv_direct_;   // the residual stream starts here
+  POOL_GET(h0, float*, (size_t)B * HW * nf_ * (hlp ? dtype_size(dtype()) : 4));
   if ((Cx == 5 || Cx == 8) && pre_conv_direct_) {
-    T2P_TRY(launch_pre_conv(x, pre_conv_direct_, pre_conv_.b, h0, B, Cx, L, L, nf_, s));
+    T2P_TRY(launch_pre_conv(x, pre_conv_direct_, pre_conv_.b, h0, hlp ? dtype() : DT_F32, B, Cx, L, L, nf_, s));
   } else {
     POOL_GET(xin, float*, (size_t)B * HW * cpad_ * 4);
     T2P_TRY(launch_nchw_to_nhwc(x, xin, B, Cx, HW, cpad_, s));
@@ -912,10 +920,18 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
     T2P_TRY(gemm(p, s));
     pool_.put(xin);
   }
+  bool h0_lowp = hlp;
+  if (res_lowp() && !hlp) {              // generic input-conv path: bring the stream to its storage type
+    POOL_GET(h0c, float*, (size_t)B * HW * nf_ * dtype_size(dtype()));
+    T2P_TRY(launch_convert(h0, h0c, dtype(), (long)B * HW * nf_, s));
+    pool_.put(h0);
+    h0 = h0c;
+    h0_lowp = true;
+  }
   pool_.put(emb); pool_.put(t1); pool_.put(t2);
 
   std::vector<Act> hs;
-  Act h{h0, nf_, L, L};
+  Act h{h0, nf_, L, L, nullptr, h0_lowp};
   hs.push_back(h);
   for (Stage& st : input_stages_) {
     T2P_TRY(run_stage(st, h, nullptr, B, s));

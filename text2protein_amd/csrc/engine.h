@@ -71,11 +71,11 @@ struct Stage {
   int skip_ch = 0;
 };
 
-struct Act {  // an NHWC fp32 activation
+struct Act {  // an NHWC activation: fp32, or the compute dtype when `lowp`
   float* p = nullptr;
   int C = 0, H = 0, W = 0;
   float* cstats = nullptr;   // optional per-64-row column sums of p (GemmParams::col_stats), for the consumer's GroupNorm
-  bool lowp = false;         // p holds compute-dtype (16-bit) values instead of fp32 (block-internal tensors only)
+  bool lowp = false;         // p holds compute-dtype (16-bit) values instead of fp32
 };
 
 class Engine {
@@ -118,7 +118,10 @@ class Engine {
   int attention(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, int B,
                 int heads, int nq, int nk, int d, float scale, hipStream_t s);
   int linear(const void* a, bool a_is_f32, const DevLinear& w, long rows, void* c, bool c_f32, const float* residual,
-             float alpha, hipStream_t s, bool use_bias = true, float** cstats = nullptr);
+             float alpha, hipStream_t s, bool use_bias = true, float** cstats = nullptr, bool r_lowp = false);
+  // the residual stream between blocks is stored in the compute dtype (f16 mode only): halves the HBM-bound
+  // traffic of GroupNorm-apply and of the residual / output halves of the block-closing GEMM epilogues
+  bool res_lowp() const { return g_lowp_residual && cfg_.compute_dtype == DT_F16; }
 
   t2p_model_config cfg_;
   std::vector<ParamInfo> params_;

@@ -18,6 +18,7 @@
 #include <array>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "t2p_common.h"
@@ -804,10 +805,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   const __amdgpu_buffer_rsrc_t rR = make_rsrc(R ? (const void*)R : (const void*)p.C, lean ? (int)r_bytes : 0);
   const bool two_b = p.bias_bn && b_edge < m0 + BM && b_edge < p.M;   // the tile spans two samples
 
-#pragma unroll
-  for (int hi = 0; hi < TI / 2; ++hi)                 // 64-row slabs of the wave tile
-#pragma unroll
-    for (int hj = 0; hj < TJ / 2; ++hj) {             // 64-column slabs
+  // One 64 x 64 slab of the wave tile.  A generic lambda called with compile-time slab indices: the
+  // accumulator arrays are then indexed by constants whatever the size of the body (a `#pragma unroll`
+  // loop this large is silently left rolled, which sends the accumulators to scratch memory).
+  auto slab = [&](auto HI, auto HJ) {
+      constexpr int hi = decltype(HI)::value, hj = decltype(HJ)::value;
       if (hi + hj > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // previous slab fully read back
       if (!(dbg & 2048)) {
       if constexpr (MF16) {
@@ -871,7 +873,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
           else { if (p.col_stats) T2P_LEAN(1, false, true); else T2P_LEAN(1, false, false); }
         }
 #undef T2P_LEAN
-        continue;
+        return;
       }
       if (ws) {                                       // split-K: raw partial sums -> workspace [split][M][N]
 #pragma unroll 4
@@ -889,7 +891,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
             if (col + 3 < p.N) dst[3] = a.w;
           }
         }
-        continue;
+        return;
       }
       const bool full4 = col + 3 < p.N;
       float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -977,7 +979,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
           *(float4*)(dst + 4) = make_float4(cs2, cq2, cs3, cq3);
         }
       }
-    }
+  };
+  slab(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  if constexpr (TJ / 2 > 1) slab(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  if constexpr (TI / 2 > 1) {
+    slab(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    if constexpr (TJ / 2 > 1) slab(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+  }
 }
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream -----------

@@ -38,6 +38,19 @@ template <> __device__ inline void store4<f16_t>(f16_t* p, float a, float b, flo
   *(h4*)p = v;
 }
 
+template <typename T> __device__ inline float4 load4(const T* p);
+template <> __device__ inline float4 load4<float>(const float* p) { return *(const float4*)p; }
+template <> __device__ inline float4 load4<bf16_t>(const bf16_t* p) {
+  const uint2 u = *(const uint2*)p;
+  return make_float4(bf16_bits_to_f32((uint16_t)u.x), bf16_bits_to_f32((uint16_t)(u.x >> 16)),
+                     bf16_bits_to_f32((uint16_t)u.y), bf16_bits_to_f32((uint16_t)(u.y >> 16)));
+}
+template <> __device__ inline float4 load4<f16_t>(const f16_t* p) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  const h4 v = *(const h4*)p;
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+
 // ================================== GroupNorm statistics ======================================
 // grid (nchunk, B, ceil(C / 1024)); each block: a slice of pixels x up to 1024 channels.  A
 // thread keeps a fixed 4-channel vector and strides over pixels (register accumulation), then
@@ -47,6 +60,7 @@ static constexpr int GN_PIX_PER_CHUNK = 256;
 
 int gn_num_chunks(int HW) { return (HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK; }
 
+template <typename TI>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormArgs a, int nchunk) {
   __shared__ float s_part[256][8];   // per thread: sum[4], sumsq[4] of its 4-channel vector
   const int C = a.C0 + a.C1;
@@ -62,15 +76,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormArgs a, int nchu
   if (tid < ppi * nvec) {
     const int v = tid % nvec, po = tid / nvec;
     const int c = c_lo + v * 4;
-    const float* src; long ld; int cc;
-    if (c < a.C0) { src = a.x0; ld = a.C0; cc = c; } else { src = a.x1; ld = a.C1; cc = c - a.C0; }
-    const float* base = src + (long)b * a.HW * ld + cc;
+    const TI* src; long ld; int cc;
+    if (c < a.C0) { src = (const TI*)a.x0; ld = a.C0; cc = c; } else { src = (const TI*)a.x1; ld = a.C1; cc = c - a.C0; }
+    const TI* base = src + (long)b * a.HW * ld + cc;
     int p = p_lo + po;
     for (; p + 3 * ppi < p_hi; p += 4 * ppi) {       // four independent 16-byte loads in flight
-      const float4 t0 = *(const float4*)(base + (long)p * ld);
-      const float4 t1 = *(const float4*)(base + (long)(p + ppi) * ld);
-      const float4 t2 = *(const float4*)(base + (long)(p + 2 * ppi) * ld);
-      const float4 t3 = *(const float4*)(base + (long)(p + 3 * ppi) * ld);
+      const float4 t0 = load4<TI>(base + (long)p * ld);
+      const float4 t1 = load4<TI>(base + (long)(p + ppi) * ld);
+      const float4 t2 = load4<TI>(base + (long)(p + 2 * ppi) * ld);
+      const float4 t3 = load4<TI>(base + (long)(p + 3 * ppi) * ld);
       s0 += (t0.x + t1.x) + (t2.x + t3.x); s1 += (t0.y + t1.y) + (t2.y + t3.y);
       s2 += (t0.z + t1.z) + (t2.z + t3.z); s3 += (t0.w + t1.w) + (t2.w + t3.w);
       q0 += (t0.x * t0.x + t1.x * t1.x) + (t2.x * t2.x + t3.x * t3.x);
@@ -79,7 +93,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GroupNormArgs a, int nchu
       q3 += (t0.w * t0.w + t1.w * t1.w) + (t2.w * t2.w + t3.w * t3.w);
     }
     for (; p < p_hi; p += ppi) {
-      const float4 t = *(const float4*)(base + (long)p * ld);
+      const float4 t = load4<TI>(base + (long)p * ld);
       s0 += t.x; s1 += t.y; s2 += t.z; s3 += t.w;
       q0 += t.x * t.x; q1 += t.y * t.y; q2 += t.z * t.z; q3 += t.w * t.w;
     }
@@ -169,7 +183,9 @@ int launch_gn_stats(const GroupNormArgs& a, hipStream_t s) {
   const int nchunk = gn_num_chunks(a.HW);
   const int ncblk = (C + 1023) / 1024;
   dim3 grid(nchunk, a.B, ncblk);
-  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, s, a, nchunk);
+  if (a.lowp_dtype == DT_F16) hipLaunchKernelGGL(gn_stats_kernel<f16_t>, grid, dim3(256), 0, s, a, nchunk);
+  else if (a.lowp_dtype == DT_BF16) hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, a, nchunk);
+  else hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, a, nchunk);
   const int tot = a.B * a.G;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 127) / 128), dim3(128), 0, s, a, nchunk * ncblk);
   T2P_HIP_CHECK(hipGetLastError());
@@ -178,19 +194,6 @@ int launch_gn_stats(const GroupNormArgs& a, hipStream_t s) {
 
 // ================================== GroupNorm apply (+SiLU, +2x2 mean) ==========================
 __device__ inline float silu_fast(float x) { return x * __frcp_rn(1.f + __expf(-x)); }
-
-template <typename T> __device__ inline float4 load4(const T* p);
-template <> __device__ inline float4 load4<float>(const float* p) { return *(const float4*)p; }
-template <> __device__ inline float4 load4<bf16_t>(const bf16_t* p) {
-  const uint2 u = *(const uint2*)p;
-  return make_float4(bf16_bits_to_f32((uint16_t)u.x), bf16_bits_to_f32((uint16_t)(u.x >> 16)),
-                     bf16_bits_to_f32((uint16_t)u.y), bf16_bits_to_f32((uint16_t)(u.y >> 16)));
-}
-template <> __device__ inline float4 load4<f16_t>(const f16_t* p) {
-  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-  const h4 v = *(const h4*)p;
-  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
-}
 
 // grid (pixel chunks, B, ceil(C / 1024)).  A thread keeps one 4-channel vector: its scale/shift
 // (rstd*gamma, beta - mean*rstd*gamma) are computed once, then it walks output pixels with 32-bit
@@ -264,7 +267,7 @@ int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s) {
   T2P_REQUIRE(!(a.down && a.raw_out), "raw copy is not produced together with down-sampling");
   const int HWo = (a.down ? a.H / 2 : a.H) * (a.down ? a.W / 2 : a.W);
   dim3 grid((HWo + GNA_PIX_PER_BLOCK - 1) / GNA_PIX_PER_BLOCK, a.B, (C + 1023) / 1024);
-  T2P_REQUIRE(!a.x0_lowp || (a.C1 == 0 && a.dtype != DT_F32), "16-bit GroupNorm input: single source, 16-bit dtype");
+  T2P_REQUIRE(!a.x0_lowp || a.dtype != DT_F32, "16-bit GroupNorm input needs a 16-bit dtype (both sources are then 16-bit)");
   switch (a.dtype) {
     case DT_F32: hipLaunchKernelGGL((gn_apply_kernel<float, float>), grid, dim3(256), 0, s, a); break;
     case DT_BF16:
@@ -354,7 +357,7 @@ int launch_gn_small(const GroupNormApplyArgs& a, hipStream_t s) {
   const int C = a.C0 + a.C1;
   T2P_REQUIRE(a.x0 && a.gamma && a.beta && a.out, "null pointer");
   T2P_REQUIRE(gn_small_eligible(a), "gn_small: not eligible");
-  T2P_REQUIRE(!a.x0_lowp || (a.C1 == 0 && a.dtype != DT_F32), "16-bit GroupNorm input: single source, 16-bit dtype");
+  T2P_REQUIRE(!a.x0_lowp || a.dtype != DT_F32, "16-bit GroupNorm input needs a 16-bit dtype (both sources are then 16-bit)");
   dim3 grid((C + 1023) / 1024, a.B);
   switch (a.dtype) {
     case DT_F32: hipLaunchKernelGGL((gn_small_kernel<float, float>), grid, dim3(256), 0, s, a); break;
@@ -538,8 +541,8 @@ int launch_geglu(const float* u, void* out, int dtype, long rows, int inner, hip
 }
 
 // ================================== 2x2 mean pooling ===================================================
-template <typename TO>
-__global__ __launch_bounds__(256) void pool2x2_kernel(const float* x, TO* out, int B, int H, int W, int C) {
+template <typename TO, typename TI>
+__global__ __launch_bounds__(256) void pool2x2_kernel(const TI* x, TO* out, int B, int H, int W, int C) {
   const int nvec = C >> 2, Ho = H >> 1, Wo = W >> 1;
   const long total = (long)B * Ho * Wo * nvec;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -548,22 +551,29 @@ __global__ __launch_bounds__(256) void pool2x2_kernel(const float* x, TO* out, i
     const int b = (int)(pix / (Ho * Wo));
     const int rem = (int)(pix - (long)b * Ho * Wo);
     const int oy = rem / Wo, ox = rem - oy * Wo;
-    const float* p = x + (((long)b * H + 2 * oy) * W + 2 * ox) * C + v * 4;
-    const float4 a = *(const float4*)p, b1 = *(const float4*)(p + C);
-    const float4 c = *(const float4*)(p + (long)W * C), d = *(const float4*)(p + (long)W * C + C);
+    const TI* p = x + (((long)b * H + 2 * oy) * W + 2 * ox) * C + v * 4;
+    const float4 a = load4<TI>(p), b1 = load4<TI>(p + C);
+    const float4 c = load4<TI>(p + (long)W * C), d = load4<TI>(p + (long)W * C + C);
     // torch.mean over the (2, 2) window: sum in row-major window order, then divide
     store4<TO>(out + pix * C + v * 4, (a.x + b1.x + c.x + d.x) * 0.25f, (a.y + b1.y + c.y + d.y) * 0.25f,
                (a.z + b1.z + c.z + d.z) * 0.25f, (a.w + b1.w + c.w + d.w) * 0.25f);
   }
 }
 
-int launch_pool2x2(const float* x, void* out, int dtype, int B, int H, int W, int C, hipStream_t s) {
+int launch_pool2x2(const float* x, void* out, int dtype, int B, int H, int W, int C, hipStream_t s, int x_lowp) {
   T2P_REQUIRE(x && out && C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "pool2x2 arguments");
+  T2P_REQUIRE(!x_lowp || dtype != DT_F32, "16-bit pooling input needs a 16-bit dtype");
   dim3 grid(ew_grid((long)B * (H / 2) * (W / 2) * (C / 4)));
   switch (dtype) {
-    case DT_F32: hipLaunchKernelGGL(pool2x2_kernel<float>, grid, dim3(256), 0, s, x, (float*)out, B, H, W, C); break;
-    case DT_BF16: hipLaunchKernelGGL(pool2x2_kernel<bf16_t>, grid, dim3(256), 0, s, x, (bf16_t*)out, B, H, W, C); break;
-    case DT_F16: hipLaunchKernelGGL(pool2x2_kernel<f16_t>, grid, dim3(256), 0, s, x, (f16_t*)out, B, H, W, C); break;
+    case DT_F32: hipLaunchKernelGGL((pool2x2_kernel<float, float>), grid, dim3(256), 0, s, x, (float*)out, B, H, W, C); break;
+    case DT_BF16:
+      if (x_lowp) hipLaunchKernelGGL((pool2x2_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, B, H, W, C);
+      else hipLaunchKernelGGL((pool2x2_kernel<bf16_t, float>), grid, dim3(256), 0, s, x, (bf16_t*)out, B, H, W, C);
+      break;
+    case DT_F16:
+      if (x_lowp) hipLaunchKernelGGL((pool2x2_kernel<f16_t, f16_t>), grid, dim3(256), 0, s, (const f16_t*)x, (f16_t*)out, B, H, W, C);
+      else hipLaunchKernelGGL((pool2x2_kernel<f16_t, float>), grid, dim3(256), 0, s, x, (f16_t*)out, B, H, W, C);
+      break;
     default: set_last_error("pool2x2: bad dtype"); return T2P_ERR_INVALID;
   }
   T2P_HIP_CHECK(hipGetLastError());
@@ -576,8 +586,8 @@ int launch_pool2x2(const float* x, void* out, int dtype, int B, int H, int W, in
 // for the MFMA GEMM (K = 45): one workgroup takes a 32-pixel row segment, stages the 3 x 34 x C
 // input patch in LDS, and each thread owns one output channel with its 9 C weights in registers;
 // lanes cover consecutive channels, so the NHWC stores are coalesced.
-template <int C>
-__global__ __launch_bounds__(256) void pre_conv_kernel(const float* x, const float* w, const float* bias, float* out, int B,
+template <int C, typename TO>
+__global__ __launch_bounds__(256) void pre_conv_kernel(const float* x, const float* w, const float* bias, TO* out, int B,
                                                        int H, int W, int nf) {
   constexpr int SEG = 32;
   __shared__ float patch[C][3][SEG + 2];
@@ -602,21 +612,26 @@ __global__ __launch_bounds__(256) void pre_conv_kernel(const float* x, const flo
       for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int c = 0; c < C; ++c) acc = fmaf(patch[c][t / 3][px + t % 3], wr[t * C + c], acc);
-      out[(((long)b * H + y) * W + x0 + px) * nf + co] = acc;
+      out[(((long)b * H + y) * W + x0 + px) * nf + co] = from_f32<TO>(acc);
     }
   }
 }
 
-int launch_pre_conv(const float* x, const float* w, const float* bias, float* out, int B, int C, int H, int W, int nf,
+int launch_pre_conv(const float* x, const float* w, const float* bias, void* out, int out_dtype, int B, int C, int H, int W, int nf,
                     hipStream_t s) {
   T2P_REQUIRE(x && w && bias && out && B > 0 && nf > 0, "pre_conv arguments");
   const int segs = (W + 31) / 32;
   dim3 grid((unsigned)((long)B * H * segs));
+#define T2P_PRE(CC)                                                                                                        \
+  if (out_dtype == DT_F16) hipLaunchKernelGGL((pre_conv_kernel<CC, f16_t>), grid, dim3(256), 0, s, x, w, bias, (f16_t*)out, B, H, W, nf); \
+  else if (out_dtype == DT_BF16) hipLaunchKernelGGL((pre_conv_kernel<CC, bf16_t>), grid, dim3(256), 0, s, x, w, bias, (bf16_t*)out, B, H, W, nf); \
+  else hipLaunchKernelGGL((pre_conv_kernel<CC, float>), grid, dim3(256), 0, s, x, w, bias, (float*)out, B, H, W, nf);
   switch (C) {
-    case 5: hipLaunchKernelGGL(pre_conv_kernel<5>, grid, dim3(256), 0, s, x, w, bias, out, B, H, W, nf); break;
-    case 8: hipLaunchKernelGGL(pre_conv_kernel<8>, grid, dim3(256), 0, s, x, w, bias, out, B, H, W, nf); break;
+    case 5: T2P_PRE(5) break;
+    case 8: T2P_PRE(8) break;
     default: set_last_error("pre_conv: only 5 or 8 input channels have a direct kernel"); return T2P_ERR_INVALID;
   }
+#undef T2P_PRE
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }

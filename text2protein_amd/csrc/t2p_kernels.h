@@ -12,6 +12,7 @@ struct GroupNormArgs {
   int B = 0, HW = 0;       // input pixels per sample
   int G = 0;
   float eps = 1e-6f;
+  int lowp_dtype = DT_F32;   // DT_F16 / DT_BF16: x0 (and x1) hold 16-bit values
   float* partial = nullptr;  // workspace [B][nchunk][G][2], nchunk = gn_num_chunks(HW)
   float* stats = nullptr;    // [B][G][2]
 };
@@ -54,10 +55,10 @@ int launch_softmax(const float* S, long lds, void* P, long ldp, int dtype, long 
 int launch_geglu(const float* u, void* out, int dtype, long rows, int inner, hipStream_t s, int interleaved = 0);
 
 // ---- 2x2 mean pooling of an NHWC fp32 map (skip branch of a down block, layers.py:309-311) ------
-int launch_pool2x2(const float* x, void* out, int dtype, int B, int H, int W, int C, hipStream_t s);
+int launch_pool2x2(const float* x, void* out, int dtype, int B, int H, int W, int C, hipStream_t s, int x_lowp = 0);
 
-// ---- pre_conv: 3x3, C in {5, 8} NCHW fp32 -> nf NHWC fp32; w = [nf][9][C] fp32 -------------------------
-int launch_pre_conv(const float* x, const float* w, const float* bias, float* out, int B, int C, int H, int W, int nf,
+// ---- pre_conv: 3x3, C in {5, 8} NCHW fp32 -> nf NHWC (fp32 or a 16-bit out_dtype); w = [nf][9][C] fp32 --
+int launch_pre_conv(const float* x, const float* w, const float* bias, void* out, int out_dtype, int B, int C, int H, int W, int nf,
                     hipStream_t s);
 
 // ---- NCHW fp32 (B,C,L,L) -> NHWC fp32 [B][L*L][Cpad], zero padded channels -----------------------
