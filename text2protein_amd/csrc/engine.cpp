@@ -762,13 +762,15 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   T2P_REQUIRE(L.ctx_k && L.ctx_vt && ctx_B_ == B, "set_context must be called with the same batch before score");
   void* a = nullptr;
   T2P_TRY(group_norm(x, nullptr, L.gn0, 1e-6f, 0, 0, B, &a, s));
-  POOL_GET(t, float*, (size_t)rows * C * 4);
-  T2P_TRY(linear(a, false, L.proj_in, rows, t, true, nullptr, 1.f, s));
+  // the block's own residual stream t: fp32, or the compute dtype together with the stream between blocks
+  const bool tl = res_lowp();
+  POOL_GET(t, float*, (size_t)rows * C * (tl ? es : 4));
+  T2P_TRY(linear(a, false, L.proj_in, rows, t, !tl, nullptr, 1.f, s));
   pool_.put(a);
   POOL_GET(ln, void*, (size_t)rows * C * es);
   POOL_GET(o, void*, (size_t)rows * C * es);
   // attn1: self-attention
-  T2P_TRY(launch_layernorm(t, L.ln1.gamma, L.ln1.beta, ln, dt, rows, C, 1e-5f, s));
+  T2P_TRY(launch_layernorm(t, L.ln1.gamma, L.ln1.beta, ln, dt, rows, C, 1e-5f, s, tl));
   {
     POOL_GET(qk, char*, (size_t)rows * 2 * C * es);
     T2P_TRY(linear(ln, false, L.a1_qk, rows, qk, false, nullptr, 1.f, s, false));
@@ -778,18 +780,18 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     pool_.put(qk);
     pool_.put(vt);
   }
-  T2P_TRY(linear(o, false, L.a1_out, rows, t, true, t, 1.f, s));
+  T2P_TRY(linear(o, false, L.a1_out, rows, t, !tl, t, 1.f, s, true, nullptr, tl));
   // attn2: cross-attention to the cached text keys / values
-  T2P_TRY(launch_layernorm(t, L.ln2.gamma, L.ln2.beta, ln, dt, rows, C, 1e-5f, s));
+  T2P_TRY(launch_layernorm(t, L.ln2.gamma, L.ln2.beta, ln, dt, rows, C, 1e-5f, s, tl));
   {
     POOL_GET(q, void*, (size_t)rows * C * es);
     T2P_TRY(linear(ln, false, L.a2_q, rows, q, false, nullptr, 1.f, s, false));
     T2P_TRY(attention(q, C, L.ctx_k, C, L.ctx_vt, ctx_Tpad_, o, B, heads, n, ctx_T_, d, scale, s));
     pool_.put(q);
   }
-  T2P_TRY(linear(o, false, L.a2_out, rows, t, true, t, 1.f, s));
+  T2P_TRY(linear(o, false, L.a2_out, rows, t, !tl, t, 1.f, s, true, nullptr, tl));
   // feed-forward with GEGLU
-  T2P_TRY(launch_layernorm(t, L.ln3.gamma, L.ln3.beta, ln, dt, rows, C, 1e-5f, s));
+  T2P_TRY(launch_layernorm(t, L.ln3.gamma, L.ln3.beta, ln, dt, rows, C, 1e-5f, s, tl));
   {
     POOL_GET(g, void*, (size_t)rows * 4 * C * es);
     GemmParams p;
@@ -805,14 +807,16 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
       T2P_TRY(launch_geglu(u, g, dt, rows, 4 * C, s, 1));
       pool_.put(u);
     }
-    T2P_TRY(linear(g, false, L.ff2, rows, t, true, t, 1.f, s));
+    T2P_TRY(linear(g, false, L.ff2, rows, t, !tl, t, 1.f, s, true, nullptr, tl));
     pool_.put(g);
   }
   pool_.put(o);
   const bool olp = res_lowp();
   POOL_GET(y, float*, (size_t)rows * C * (olp ? es : 4));
   float* y_stats = nullptr;
-  if (dt != DT_F32 && g_raw_copies) {
+  if (tl) {                                              // t already is a GEMM operand
+    T2P_TRY(linear(t, false, L.proj_out, rows, y, !olp, x.p, 1.f, s, true, &y_stats, x.lowp));
+  } else if (dt != DT_F32 && g_raw_copies) {
     T2P_TRY(launch_convert(t, ln, dt, rows * C, s));     // residual stream -> compute dtype (reuses the LN buffer)
     T2P_TRY(linear(ln, false, L.proj_out, rows, y, !olp, x.p, 1.f, s, true, &y_stats, x.lowp));
   } else {

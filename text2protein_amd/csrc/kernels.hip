@@ -377,28 +377,28 @@ int launch_gn_small(const GroupNormApplyArgs& a, hipStream_t s) {
 
 // ================================== LayerNorm ====================================================
 // one wavefront per row; three passes over an L1/L2-resident row (C <= a few thousand).
-template <typename TO>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* gamma, const float* beta,
+template <typename TO, typename TI>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* x, const float* gamma, const float* beta,
                                                         TO* out, long rows, int C, float eps) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
-  const float* xr = x + row * C;
+  const TI* xr = x + row * C;
   float s = 0.f;
   for (int c = lane * 4; c < C; c += 256) {
-    float4 t = *(const float4*)(xr + c);
+    float4 t = load4<TI>(xr + c);
     s += (t.x + t.y) + (t.z + t.w);
   }
   const float mean = wave_sum(s) / C;
   float q = 0.f;
   for (int c = lane * 4; c < C; c += 256) {
-    float4 t = *(const float4*)(xr + c);
+    float4 t = load4<TI>(xr + c);
     float a0 = t.x - mean, a1 = t.y - mean, a2 = t.z - mean, a3 = t.w - mean;
     q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
   }
   const float rstd = 1.f / sqrtf(wave_sum(q) / C + eps);
   for (int c = lane * 4; c < C; c += 256) {
-    float4 t = *(const float4*)(xr + c);
+    float4 t = load4<TI>(xr + c);
     float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
     store4<TO>(out + row * C + c, (t.x - mean) * rstd * g.x + b.x, (t.y - mean) * rstd * g.y + b.y,
                (t.z - mean) * rstd * g.z + b.z, (t.w - mean) * rstd * g.w + b.w);
@@ -406,13 +406,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
 }
 
 int launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int dtype, long rows, int C,
-                     float eps, hipStream_t s) {
+                     float eps, hipStream_t s, int x_lowp) {
   T2P_REQUIRE(x && gamma && beta && out && C % 4 == 0 && rows > 0, "layernorm arguments");
+  T2P_REQUIRE(!x_lowp || dtype != DT_F32, "16-bit LayerNorm input needs a 16-bit dtype");
   dim3 grid((unsigned)((rows + 3) / 4));
   switch (dtype) {
-    case DT_F32: hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, x, gamma, beta, (float*)out, rows, C, eps); break;
-    case DT_BF16: hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, s, x, gamma, beta, (bf16_t*)out, rows, C, eps); break;
-    case DT_F16: hipLaunchKernelGGL(layernorm_kernel<f16_t>, grid, dim3(256), 0, s, x, gamma, beta, (f16_t*)out, rows, C, eps); break;
+    case DT_F32: hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, dim3(256), 0, s, x, gamma, beta, (float*)out, rows, C, eps); break;
+    case DT_BF16:
+      if (x_lowp) hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)out, rows, C, eps);
+      else hipLaunchKernelGGL((layernorm_kernel<bf16_t, float>), grid, dim3(256), 0, s, x, gamma, beta, (bf16_t*)out, rows, C, eps);
+      break;
+    case DT_F16:
+      if (x_lowp) hipLaunchKernelGGL((layernorm_kernel<f16_t, f16_t>), grid, dim3(256), 0, s, (const f16_t*)x, gamma, beta, (f16_t*)out, rows, C, eps);
+      else hipLaunchKernelGGL((layernorm_kernel<f16_t, float>), grid, dim3(256), 0, s, x, gamma, beta, (f16_t*)out, rows, C, eps);
+      break;
     default: set_last_error("layernorm: bad dtype"); return T2P_ERR_INVALID;
   }
   T2P_HIP_CHECK(hipGetLastError());

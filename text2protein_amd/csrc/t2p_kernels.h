@@ -45,7 +45,7 @@ int launch_gn_small(const GroupNormApplyArgs& a, hipStream_t s);
 
 // ---- LayerNorm over the last axis (attention.py:203-205), eps 1e-5 ---------------------------
 int launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int dtype,
-                     long rows, int C, float eps, hipStream_t s);
+                     long rows, int C, float eps, hipStream_t s, int x_lowp = 0);
 
 // ---- row softmax: P[r][0:n] = softmax(scale * S[r][0:n]); P[r][n:ldp] = 0 ----------------------
 int launch_softmax(const float* S, long lds, void* P, long ldp, int dtype, long rows, int n, float scale,
