@@ -627,6 +627,7 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
   // shortcut branch
   const float* r = x.p;
   float* rbuf = nullptr;
+  bool rbuf_lowp = false;
   int r_up = 0;
   if (L.has_conv2) {
     GemmParams p;
@@ -650,10 +651,11 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
       rrows = (long)B * x.H * x.W;   // for `up` the 1x1 conv runs at the low resolution: it commutes
       r_up = L.up;                   // with nearest up-sampling exactly
     }
-    rbuf = (float*)pool_.get((size_t)rrows * Cout * 4);
+    rbuf_lowp = false;   // the shortcut output stays fp32: storing it in 16 bits measured no gain and costs accuracy
+    rbuf = (float*)pool_.get((size_t)rrows * Cout * (rbuf_lowp ? dtype_size(dt) : 4));
     if (!rbuf) return T2P_ERR_HIP;
     p.Bw = L.conv2.w; p.ldb = L.conv2.K; p.M = (int)rrows; p.N = Cout; p.bias_n = L.conv2.b;
-    p.C = rbuf; p.c_f32 = 1; p.ldc = Cout;
+    p.C = rbuf; p.c_f32 = rbuf_lowp ? 0 : 1; p.ldc = Cout;
     T2P_TRY(gemm(p, s));
     pool_.put(pooled);
     pool_.put(xraw);
@@ -671,7 +673,7 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     p.Bw = L.conv1.w; p.ldb = L.conv1.K; p.M = (int)rows_out; p.N = Cout;
     p.bias_n = L.conv1.b; p.rows_per_batch = Ho * Wo;
     p.R = r; p.ldr = Cout; p.r_up = r_up;
-    p.r_lowp = (r == x.p && x.lowp) ? 1 : 0;          // identity shortcut: the block input itself; conv2 output is fp32
+    p.r_lowp = (r == x.p ? x.lowp : rbuf_lowp) ? 1 : 0;   // identity shortcut: the block input itself
     p.alpha = cfg_.skip_rescale ? 0.70710678118654752440f : 1.f;
     p.C = o; p.c_f32 = olp ? 0 : 1; p.ldc = Cout;
     T2P_TRY(gemm_stats(p, &o_stats, s));

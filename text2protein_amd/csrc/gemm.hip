@@ -376,11 +376,14 @@ template <int I> __device__ inline void lds_read_b128_2k(u32x4_t& dst, unsigned 
 // loop is branch-free: 8 LDS reads and (HAS_R) 8 residual loads at a time are in flight before the
 // first use.  OUT: 0 fp32, 1 compute dtype, 2 GEGLU (interleaved value / gate columns ->
 // compute dtype), 3 raw split-K partial.  Every variant issues exactly 16 stores.
+// residual stored at half resolution (up-sampling blocks): row (b, y, x) reads residual row (b, y / 2, x / 2)
+struct LeanRup { int on, W, HW, b_first, b_edge, hw4, w2; unsigned row_bytes, col_bytes; };
+
 template <typename TC, int OUT, bool HAS_R, bool STATS, bool RL = false>
 __device__ __forceinline__ void lean_slab(const float* sp, const __amdgpu_buffer_rsrc_t rC, const __amdgpu_buffer_rsrc_t rR,
                                           unsigned voc, const unsigned stc, unsigned vor, const unsigned str,
                                           const float4 bn0, const float4 bn1, const int row_first, const int b_edge,
-                                          const float alpha, float* stats_dst) {
+                                          const float alpha, float* stats_dst, const LeanRup rup) {
   if constexpr (OUT == 3) {
 #pragma unroll
     for (int h8 = 0; h8 < 2; ++h8) {
@@ -406,9 +409,17 @@ __device__ __forceinline__ void lean_slab(const float* sp, const __amdgpu_buffer
     if constexpr (HAS_R) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        if constexpr (RL) rv[i] = unpack4<TC>(__builtin_amdgcn_raw_buffer_load_b64(rR, vor, 0, 0));   // 16-bit residual
-        else rv[i] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rR, vor, 0, 0));
-        vor += str;
+        unsigned off = vor;
+        if (rup.on) {                                  // wave-uniform; a tile spans at most two samples
+          const int row = row_first + 4 * (h8 * 8 + i);
+          const int bidx = rup.b_first + (row >= rup.b_edge ? 1 : 0);
+          const int rem = row - bidx * rup.HW;
+          const int y = rem / rup.W, x = rem - y * rup.W;
+          off = vor == DMA_OOB ? DMA_OOB : (unsigned)(bidx * rup.hw4 + (y >> 1) * rup.w2 + (x >> 1)) * rup.row_bytes + rup.col_bytes;
+        }
+        if constexpr (RL) rv[i] = unpack4<TC>(__builtin_amdgcn_raw_buffer_load_b64(rR, off, 0, 0));   // 16-bit residual
+        else rv[i] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rR, off, 0, 0));
+        if (!rup.on) vor += str;
       }
     }
 #pragma unroll
@@ -796,9 +807,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   // (row bias, up-sampled residual, samples shorter than a tile, unaligned strides, >= 2 GiB operands).
   const int c_cols = p.geglu ? p.N / 2 : p.N;
   const long c_bytes = ws ? (long)p.M * p.N * 4 : ((long)(p.M - 1) * p.ldc + c_cols) * (p.c_f32 ? 4 : 2);
-  const long r_bytes = R ? ((long)(p.M - 1) * p.ldr + p.N) * (p.r_lowp ? 2 : 4) : 0;
+  const long r_rows = p.r_up ? (long)(p.M / HW) * (p.H >> 1) * (p.W >> 1) : (long)p.M;
+  const long r_bytes = R ? ((r_rows - 1) * p.ldr + p.N) * (p.r_lowp ? 2 : 4) : 0;
   const bool lean = !(dbg & 512) && (p.N & 3) == 0 && c_bytes < (1L << 31) && r_bytes < (1L << 31) &&
-                    (ws != nullptr || (!p.bias_m && !p.r_up && (!need_b || rpb >= BM) && (p.geglu ? p.ldc % 2 == 0 : p.ldc % 4 == 0) &&
+                    (ws != nullptr || (!p.bias_m && (!need_b || rpb >= BM) && (p.geglu ? p.ldc % 2 == 0 : p.ldc % 4 == 0) &&
                                        (!R || p.ldr % 4 == 0) && (!p.bias_bn || p.ld_bn % 4 == 0)));
   const __amdgpu_buffer_rsrc_t rC =
       make_rsrc(ws ? (const void*)ws : (p.c_f32 ? (const void*)((float*)p.C + coff) : (const void*)((TC*)p.C + coff)), lean ? (int)c_bytes : 0);
@@ -845,6 +857,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
         const unsigned rsz = p.r_lowp ? 2u : 4u;
         const unsigned vor = col_ok ? ((unsigned)(row0 + rq) * (unsigned)p.ldr + (unsigned)col) * rsz : DMA_OOB;
         const unsigned str = 4u * rsz * (unsigned)p.ldr;
+        const LeanRup rup = {p.r_up, p.W, HW, b_first, b_edge, (p.H >> 1) * (p.W >> 1), p.W >> 1, rsz * (unsigned)p.ldr, rsz * (unsigned)col};
         float4 bn0 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!ws && p.bias_n && col_ok) bn0 = *(const float4*)(p.bias_n + col);
         float4 bn1 = bn0;
@@ -860,8 +873,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
         float* sd = (p.col_stats && lane < 16 && col_ok && row0 < p.M) ? p.col_stats + ((long)(row0 >> 6) * p.N + col) * 2 : nullptr;
 #define T2P_LEAN(OUT, HR, ST)                                                                                             \
   do {                                                                                                                   \
-    if (HR && p.r_lowp) lean_slab<TC, OUT, HR, ST, HR>(sp, rC, rR, voc, stc, vor, str, bn0, bn1, row0 + rq, edge, p.alpha, sd); \
-    else lean_slab<TC, OUT, HR, ST, false>(sp, rC, rR, voc, stc, vor, str, bn0, bn1, row0 + rq, edge, p.alpha, sd);      \
+    if (HR && p.r_lowp) lean_slab<TC, OUT, HR, ST, HR>(sp, rC, rR, voc, stc, vor, str, bn0, bn1, row0 + rq, edge, p.alpha, sd, rup); \
+    else lean_slab<TC, OUT, HR, ST, false>(sp, rC, rR, voc, stc, vor, str, bn0, bn1, row0 + rq, edge, p.alpha, sd, rup); \
   } while (0)
         if (ws) T2P_LEAN(3, false, false);
         else if (p.geglu) T2P_LEAN(2, false, false);
