@@ -201,7 +201,7 @@ __device__ inline float silu_fast(float x) { return x * __frcp_rn(1.f + __expf(-
 static constexpr int GNA_PIX_PER_BLOCK = 64;
 
 template <typename TO, typename TI>
-__global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormApplyArgs a) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormApplyArgs a, int pix_per_block) {
   const int C = a.C0 + a.C1;
   const int Ho = a.down ? a.H >> 1 : a.H, Wo = a.down ? a.W >> 1 : a.W;
   const int HWo = Ho * Wo;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormApplyArgs a) {
   }
   TO* out = (TO*)a.out + (long)b * HWo * C + c;
   TO* raw = a.raw_out ? (TO*)a.raw_out + (long)b * HWo * C + c : nullptr;
-  const int p_lo = blockIdx.x * GNA_PIX_PER_BLOCK, p_hi = min(HWo, p_lo + GNA_PIX_PER_BLOCK);
+  const int p_lo = blockIdx.x * pix_per_block, p_hi = min(HWo, p_lo + pix_per_block);
   if (!a.down) {
 #pragma unroll 2
     for (int p = p_lo + po; p < p_hi; p += ppi) {
@@ -266,17 +266,24 @@ int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s) {
   T2P_REQUIRE(!a.down || (a.H % 2 == 0 && a.W % 2 == 0), "down-sampling needs even H, W");
   T2P_REQUIRE(!(a.down && a.raw_out), "raw copy is not produced together with down-sampling");
   const int HWo = (a.down ? a.H / 2 : a.H) * (a.down ? a.W / 2 : a.W);
-  dim3 grid((HWo + GNA_PIX_PER_BLOCK - 1) / GNA_PIX_PER_BLOCK, a.B, (C + 1023) / 1024);
+  // pixels per block: 64 on large maps; on small maps fewer, so that the launch still has ~2048 blocks
+  // (a 16x16 map with 64 pixels per block is 128 blocks of 32 serial iterations: latency-bound)
+  const int zb = (C + 1023) / 1024;
+  const int ppi = 256 / (std::min(C, 1024) / 4);                       // pixels a block covers per iteration
+  long want = ((long)HWo * a.B * zb + 2047) / 2048;
+  int ppb = (int)std::min<long>(GNA_PIX_PER_BLOCK, std::max<long>(want, std::max(ppi, 1)));
+  if (ppi > 1) ppb = (ppb + ppi - 1) / ppi * ppi;
+  dim3 grid((HWo + ppb - 1) / ppb, a.B, zb);
   T2P_REQUIRE(!a.x0_lowp || a.dtype != DT_F32, "16-bit GroupNorm input needs a 16-bit dtype (both sources are then 16-bit)");
   switch (a.dtype) {
-    case DT_F32: hipLaunchKernelGGL((gn_apply_kernel<float, float>), grid, dim3(256), 0, s, a); break;
+    case DT_F32: hipLaunchKernelGGL((gn_apply_kernel<float, float>), grid, dim3(256), 0, s, a, ppb); break;
     case DT_BF16:
-      if (a.x0_lowp) hipLaunchKernelGGL((gn_apply_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((gn_apply_kernel<bf16_t, float>), grid, dim3(256), 0, s, a);
+      if (a.x0_lowp) hipLaunchKernelGGL((gn_apply_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, a, ppb);
+      else hipLaunchKernelGGL((gn_apply_kernel<bf16_t, float>), grid, dim3(256), 0, s, a, ppb);
       break;
     case DT_F16:
-      if (a.x0_lowp) hipLaunchKernelGGL((gn_apply_kernel<f16_t, f16_t>), grid, dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((gn_apply_kernel<f16_t, float>), grid, dim3(256), 0, s, a);
+      if (a.x0_lowp) hipLaunchKernelGGL((gn_apply_kernel<f16_t, f16_t>), grid, dim3(256), 0, s, a, ppb);
+      else hipLaunchKernelGGL((gn_apply_kernel<f16_t, float>), grid, dim3(256), 0, s, a, ppb);
       break;
     default: set_last_error("gn_apply: bad dtype"); return T2P_ERR_INVALID;
   }
@@ -291,12 +298,14 @@ int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s) {
 // group are folded in a fixed order through LDS (double, like gn_finalize), pass 2 re-reads the
 // (L2-resident) map and writes the normalised / activated result.  Same thread -> (channel, pixel)
 // mapping as gn_apply_kernel.
+struct GnSmallArgs : GroupNormApplyArgs { int cb = 1024; };   // cb: channels per block (whole groups)
+
 template <typename TO, typename TI>
-__global__ __launch_bounds__(256) void gn_small_kernel(GroupNormApplyArgs a) {
+__global__ __launch_bounds__(256) void gn_small_kernel(GnSmallArgs a) {
   __shared__ float part[256][8];
   const int C = a.C0 + a.C1, HW = a.H * a.W;
-  const int b = blockIdx.y, c_lo = blockIdx.x * 1024;
-  const int nvec = min(C - c_lo, 1024) >> 2;
+  const int b = blockIdx.y, c_lo = blockIdx.x * a.cb;
+  const int nvec = min(C - c_lo, a.cb) >> 2;
   const int ppi = 256 / nvec;
   const int tid = threadIdx.x;
   const bool active = tid < ppi * nvec;
@@ -345,12 +354,19 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GroupNormApplyArgs a) {
   }
 }
 
+// channels per block: whole groups, about 128 (more blocks = shorter serial loops; 32 blocks of 1024
+// channels took 18 us on a few KiB)
+static int gn_small_cb(int C, int cpg) {
+  if (C <= 128) return C;
+  return (128 % cpg == 0) ? 128 : ((128 + cpg - 1) / cpg) * cpg;
+}
+
 bool gn_small_eligible(const GroupNormApplyArgs& a) {
   const int C = a.C0 + a.C1;
   if (a.down || a.G <= 0 || C % a.G != 0 || a.H * a.W > 64) return false;
   const int cpg = C / a.G;
   if (cpg % 4 != 0 || a.C0 % 4 != 0 || a.C1 % 4 != 0) return false;
-  return C <= 1024 || 1024 % cpg == 0;               // a block's 1024 channels hold whole groups
+  return gn_small_cb(C, cpg) <= 1024;
 }
 
 int launch_gn_small(const GroupNormApplyArgs& a, hipStream_t s) {
@@ -358,16 +374,19 @@ int launch_gn_small(const GroupNormApplyArgs& a, hipStream_t s) {
   T2P_REQUIRE(a.x0 && a.gamma && a.beta && a.out, "null pointer");
   T2P_REQUIRE(gn_small_eligible(a), "gn_small: not eligible");
   T2P_REQUIRE(!a.x0_lowp || a.dtype != DT_F32, "16-bit GroupNorm input needs a 16-bit dtype (both sources are then 16-bit)");
-  dim3 grid((C + 1023) / 1024, a.B);
+  GnSmallArgs g;
+  (GroupNormApplyArgs&)g = a;
+  g.cb = gn_small_cb(C, C / a.G);
+  dim3 grid((C + g.cb - 1) / g.cb, a.B);
   switch (a.dtype) {
-    case DT_F32: hipLaunchKernelGGL((gn_small_kernel<float, float>), grid, dim3(256), 0, s, a); break;
+    case DT_F32: hipLaunchKernelGGL((gn_small_kernel<float, float>), grid, dim3(256), 0, s, g); break;
     case DT_BF16:
-      if (a.x0_lowp) hipLaunchKernelGGL((gn_small_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((gn_small_kernel<bf16_t, float>), grid, dim3(256), 0, s, a);
+      if (a.x0_lowp) hipLaunchKernelGGL((gn_small_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((gn_small_kernel<bf16_t, float>), grid, dim3(256), 0, s, g);
       break;
     case DT_F16:
-      if (a.x0_lowp) hipLaunchKernelGGL((gn_small_kernel<f16_t, f16_t>), grid, dim3(256), 0, s, a);
-      else hipLaunchKernelGGL((gn_small_kernel<f16_t, float>), grid, dim3(256), 0, s, a);
+      if (a.x0_lowp) hipLaunchKernelGGL((gn_small_kernel<f16_t, f16_t>), grid, dim3(256), 0, s, g);
+      else hipLaunchKernelGGL((gn_small_kernel<f16_t, float>), grid, dim3(256), 0, s, g);
       break;
     default: set_last_error("gn_small: bad dtype"); return T2P_ERR_INVALID;
   }
