@@ -1132,26 +1132,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
   }
 }
 
-// Vectorised second pass: a 256-thread block owns RPT*16 rows x 64 columns; thread (rl = t >> 4, cg = t & 15)
-// sums the partials of 4 columns of rows rl + 16 i in split order (bitwise reproducible), applies the
-// epilogue and, with RPT == 4 (64-row blocks = the statistics chunk), the GroupNorm column statistics of
-// the final fp32 values, folded over the 16 row lanes in a fixed order through LDS.
-template <typename TC, int RPT>
-__global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmParams p, const int nsplit) {
-  __shared__ float red[16][16][8];
+// Vectorised second pass: a block of 16 * RL threads owns RL rows x 64 columns (RL = 64: the statistics
+// chunk, 1024 threads; RL = 16: 256 threads); thread (rl = t >> 4, cg = t & 15) sums the partials of 4
+// columns of its row in split order (bitwise reproducible), applies the epilogue and, with RL == 64, the
+// GroupNorm column statistics of the final fp32 values, folded over the row lanes in a fixed order
+// through LDS.  One row per thread: these launches are small, so parallelism beats work per thread.
+template <typename TC, int RL>
+__global__ __launch_bounds__(16 * RL) void splitk_reduce_vec_kernel(const GemmParams p, const int nsplit) {
+  __shared__ float red[RL == 64 ? 64 : 1][16][8];
   const int t = threadIdx.x, cg = t & 15, rl = t >> 4;
   const int col = blockIdx.x * 64 + cg * 4;
-  const int row0 = blockIdx.y * (RPT * 16);
+  const int row0 = blockIdx.y * RL;
   const long total = (long)p.M * p.N;
   const int HW = p.H * p.W;
   const bool col_ok = col < p.N;
-  float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias_n && col_ok) bn = *(const float4*)(p.bias_n + col);
+  const int row = row0 + rl;
   float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const int row = row0 + rl + 16 * i;
-    if (row >= p.M || !col_ok) continue;
+  if (row < p.M && col_ok) {
+    float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias_n) bn = *(const float4*)(p.bias_n + col);
     const float* src = (const float*)p.ws + (long)row * p.N + col;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);       // 0 + p0 is exact: same sums as starting from p0
     int k = 0;
@@ -1189,25 +1188,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const GemmParams
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     a.x *= p.alpha; a.y *= p.alpha; a.z *= p.alpha; a.w *= p.alpha;
-    cs[0] += a.x; cs[1] += a.y; cs[2] += a.z; cs[3] += a.w;
-    cq[0] += a.x * a.x; cq[1] += a.y * a.y; cq[2] += a.z * a.z; cq[3] += a.w * a.w;
+    cs[0] = a.x; cs[1] = a.y; cs[2] = a.z; cs[3] = a.w;
+    cq[0] = a.x * a.x; cq[1] = a.y * a.y; cq[2] = a.z * a.z; cq[3] = a.w * a.w;
     if (p.c_f32) *(float4*)((float*)p.C + (long)row * p.ldc + col) = a;
     else *(u32x2_t*)((TC*)p.C + (long)row * p.ldc + col) = (u32x2_t){pack2<TC>(a.x, a.y), pack2<TC>(a.z, a.w)};
   }
-  if (RPT == 4 && p.col_stats) {
+  if constexpr (RL == 64) {
+    if (p.col_stats) {                                 // uniform
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { red[rl][cg][2 * k] = cs[k]; red[rl][cg][2 * k + 1] = cq[k]; }
-    __syncthreads();
-    if (rl == 0 && col_ok && row0 < p.M) {
-      float o[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = red[0][cg][k];
-      for (int r = 1; r < 16; ++r)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] += red[r][cg][k];
-      float* dst = p.col_stats + ((long)(row0 >> 6) * p.N + col) * 2;
-      *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-      *(float4*)(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      for (int k = 0; k < 4; ++k) { red[rl][cg][2 * k] = cs[k]; red[rl][cg][2 * k + 1] = cq[k]; }
+      __syncthreads();
+      if (t < 128) {                                   // (cg, k): 16 column groups x 8 values, rows folded in order
+        const int c2 = t >> 3, k2 = t & 7;
+        float o = red[0][c2][k2];
+        for (int r = 1; r < 64; ++r) o += red[r][c2][k2];
+        const int ccol = blockIdx.x * 64 + c2 * 4;
+        if (ccol < p.N && row0 < p.M) p.col_stats[((long)(row0 >> 6) * p.N + ccol) * 2 + k2] = o;
+      }
     }
   }
 }
@@ -1333,8 +1330,8 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
       // 64 x 64 output blocks when column statistics are wanted (their chunking), 16 x 64 otherwise
       const int rows = (p.col_stats || (long)p.M * p.N >= (1L << 22)) ? 64 : 16;
       dim3 g((p.N + 63) / 64, (p.M + rows - 1) / rows);
-      if (rows == 64) hipLaunchKernelGGL((splitk_reduce_vec_kernel<TC, 4>), g, dim3(256), 0, stream, p, nsplit);
-      else hipLaunchKernelGGL((splitk_reduce_vec_kernel<TC, 1>), g, dim3(256), 0, stream, p, nsplit);
+      if (rows == 64) hipLaunchKernelGGL((splitk_reduce_vec_kernel<TC, 64>), g, dim3(1024), 0, stream, p, nsplit);
+      else hipLaunchKernelGGL((splitk_reduce_vec_kernel<TC, 16>), g, dim3(256), 0, stream, p, nsplit);
     } else {
       const long total = (long)p.M * p.N;
       const int g = (int)std::min<long>((total + 255) / 256, 4096);
