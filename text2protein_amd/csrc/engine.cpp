@@ -385,7 +385,11 @@ int Engine::finalize() {
     const HostTensor* w = host("pre_conv.weight", {nf_, cfg_.num_channels, 3, 3});
     if (!w) return T2P_ERR_STATE;
     std::vector<float> m = to_nk(*w, true, false, 0);      // [nf][tap][C], unpadded
-    T2P_TRY(upload_f32(m, &pre_conv_direct_));
+    const int K9 = 9 * cfg_.num_channels;
+    std::vector<float> mt((size_t)K9 * nf_);                // [tap][C][nf]: lanes (= output channels) read contiguously
+    for (int n = 0; n < nf_; ++n)
+      for (int k = 0; k < K9; ++k) mt[(size_t)k * nf_ + n] = m[(size_t)n * K9 + k];
+    T2P_TRY(upload_f32(mt, &pre_conv_direct_));
   }
   std::vector<float> dw((size_t)temb_total_ * td), db(temb_total_);
   auto each_layer = [&](auto&& fn) -> int {

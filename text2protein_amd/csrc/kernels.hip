@@ -612,33 +612,59 @@ int launch_pool2x2(const float* x, void* out, int dtype, int B, int H, int W, in
 // for the MFMA GEMM (K = 45): one workgroup takes a 32-pixel row segment, stages the 3 x 34 x C
 // input patch in LDS, and each thread owns one output channel with its 9 C weights in registers;
 // lanes cover consecutive channels, so the NHWC stores are coalesced.
+static constexpr int PRE_ROWS = 4;   // image rows per block: the per-thread weights are loaded once for all of them
+
 template <int C, typename TO>
 __global__ __launch_bounds__(256) void pre_conv_kernel(const float* x, const float* w, const float* bias, TO* out, int B,
                                                        int H, int W, int nf) {
-  constexpr int SEG = 32;
-  __shared__ float patch[C][3][SEG + 2];
-  const int segs = (W + SEG - 1) / SEG;
-  const int seg = blockIdx.x % segs, y = (blockIdx.x / segs) % H, b = blockIdx.x / (segs * H);
+  constexpr int SEG = 32, ROW = 40;                    // patch rows padded to 16-byte multiples (34 used + 6)
+  __shared__ __attribute__((aligned(16))) float patch[C][3][ROW];
+  const int segs = (W + SEG - 1) / SEG, rblks = (H + PRE_ROWS - 1) / PRE_ROWS;
+  const int seg = blockIdx.x % segs, yb = (blockIdx.x / segs) % rblks, b = blockIdx.x / (segs * rblks);
   const int x0 = seg * SEG;
-  for (int i = threadIdx.x; i < C * 3 * (SEG + 2); i += 256) {
-    const int c = i / (3 * (SEG + 2)), r = (i / (SEG + 2)) % 3, col = i % (SEG + 2);
-    const int sy = y + r - 1, sx = x0 + col - 1;
-    patch[c][r][col] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[(((long)b * C + c) * H + sy) * W + sx] : 0.f;
-  }
-  __syncthreads();
-  for (int co = threadIdx.x; co < nf; co += 256) {
+  // a thread owns one output channel (its 9 C weights in registers; w is [tap][c][nf], so a wavefront reads each
+  // of them as one contiguous row) and 4 consecutive pixels at a time: the 3-tap window of 4 pixels is 6
+  // consecutive patch values = two 16-byte LDS reads for 12 FMAs (a read per FMA made the kernel LDS-issue-bound).
+  // With nf <= 128 the block splits the segment into pixel groups so that all 256 threads work.
+  const int ngrp = nf >= 256 ? 1 : (256 / nf >= 8 ? 8 : 256 / nf);
+  const int pg = SEG / ngrp;                           // pixels per group: 32, 16, 8 or 4
+  const int npx = min(SEG, W - x0);
+  for (int co0 = 0; co0 < nf; co0 += 256) {
+    const int co = co0 + (ngrp == 1 ? (int)threadIdx.x : (int)threadIdx.x % nf);
+    const int grp = ngrp == 1 ? 0 : (int)threadIdx.x / nf;
+    const bool work = co < nf && grp < ngrp;
     float wr[C * 9];
 #pragma unroll
-    for (int i = 0; i < C * 9; ++i) wr[i] = w[(long)co * 9 * C + i];       // [co][tap][c]
-    const float bv = bias[co];
-    const int npx = min(SEG, W - x0);
-    for (int px = 0; px < npx; ++px) {
-      float acc = bv;
+    for (int i = 0; i < C * 9; ++i) wr[i] = work ? w[(long)i * nf + co] : 0.f;
+    const float bv = work ? bias[co] : 0.f;
+    for (int y = yb * PRE_ROWS; y < min(H, (yb + 1) * PRE_ROWS); ++y) {
+      __syncthreads();                                 // the previous row's patch is no longer read
+      for (int i = threadIdx.x; i < C * 3 * ROW; i += 256) {
+        const int c = i / (3 * ROW), r = (i / ROW) % 3, col = i % ROW;
+        const int sy = y + r - 1, sx = x0 + col - 1;
+        patch[c][r][col] = (col < SEG + 2 && sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[(((long)b * C + c) * H + sy) * W + sx] : 0.f;
+      }
+      __syncthreads();
+      if (!work) continue;
+      for (int px = grp * pg; px < (grp + 1) * pg && px < npx; px += 4) {
+        float a0 = bv, a1 = bv, a2 = bv, a3 = bv;
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t) {                  // tap-major, channel-minor: the summation order of a plain loop
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc = fmaf(patch[c][t / 3][px + t % 3], wr[t * C + c], acc);
-      out[(((long)b * H + y) * W + x0 + px) * nf + co] = from_f32<TO>(acc);
+          for (int c = 0; c < C; ++c) {
+            const float4 p0 = *(const float4*)&patch[c][t / 3][px], p1 = *(const float4*)&patch[c][t / 3][px + 4];
+            const float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+            const float wv = wr[t * C + c];
+            a0 = fmaf(v[t % 3], wv, a0); a1 = fmaf(v[t % 3 + 1], wv, a1);
+            a2 = fmaf(v[t % 3 + 2], wv, a2); a3 = fmaf(v[t % 3 + 3], wv, a3);
+          }
+        }
+        TO* o = out + (((long)b * H + y) * W + x0 + px) * nf + co;
+        o[0] = from_f32<TO>(a0);
+        if (px + 1 < npx) o[(long)nf] = from_f32<TO>(a1);
+        if (px + 2 < npx) o[2L * nf] = from_f32<TO>(a2);
+        if (px + 3 < npx) o[3L * nf] = from_f32<TO>(a3);
+      }
     }
   }
 }
@@ -647,7 +673,7 @@ int launch_pre_conv(const float* x, const float* w, const float* bias, void* out
                     hipStream_t s) {
   T2P_REQUIRE(x && w && bias && out && B > 0 && nf > 0, "pre_conv arguments");
   const int segs = (W + 31) / 32;
-  dim3 grid((unsigned)((long)B * H * segs));
+  dim3 grid((unsigned)((long)B * ((H + PRE_ROWS - 1) / PRE_ROWS) * segs));
 #define T2P_PRE(CC)                                                                                                        \
   if (out_dtype == DT_F16) hipLaunchKernelGGL((pre_conv_kernel<CC, f16_t>), grid, dim3(256), 0, s, x, w, bias, (f16_t*)out, B, H, W, nf); \
   else if (out_dtype == DT_BF16) hipLaunchKernelGGL((pre_conv_kernel<CC, bf16_t>), grid, dim3(256), 0, s, x, w, bias, (bf16_t*)out, B, H, W, nf); \

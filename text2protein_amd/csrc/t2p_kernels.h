@@ -57,7 +57,7 @@ int launch_geglu(const float* u, void* out, int dtype, long rows, int inner, hip
 // ---- 2x2 mean pooling of an NHWC fp32 map (skip branch of a down block, layers.py:309-311) ------
 int launch_pool2x2(const float* x, void* out, int dtype, int B, int H, int W, int C, hipStream_t s, int x_lowp = 0);
 
-// ---- pre_conv: 3x3, C in {5, 8} NCHW fp32 -> nf NHWC (fp32 or a 16-bit out_dtype); w = [nf][9][C] fp32 --
+// ---- pre_conv: 3x3, C in {5, 8} NCHW fp32 -> nf NHWC (fp32 or a 16-bit out_dtype); w = [9][C][nf] fp32 (tap-major, output channel contiguous) --
 int launch_pre_conv(const float* x, const float* w, const float* bias, void* out, int out_dtype, int B, int C, int H, int W, int nf,
                     hipStream_t s);
 
