@@ -74,3 +74,30 @@ def test_score_wide_config_matches_oracle(dtype):
     err = rel_l2(got.cpu(), want)
     print(f"wide config {dtype}: score rel-L2 vs oracle = {err:.3e}")
     assert err < SCORE_TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_head_conv_thin_kernel_matches_gemm_path(dtype):
+    """The network head (nf -> 5 channels, NCHW fp32 output x 1/sigma) on the thin-output MFMA kernel against the
+    same layer on the generic GEMM kernel (development key 15): identical 16-bit operands, fp32 accumulation in
+    a different order.  Ragged tiles: a 24 x 24 map is 3 x 2 tiles of 8 x 16 with half-empty columns."""
+    from text2protein_amd import _lib, synth
+    from text2protein_amd.config import tiny_config
+    lib = _lib.load()
+    cfg = tiny_config(**{"data.max_res_num": 24, "model.attn_resolutions": [12], "model.nf": 64, "model.ch_mult": [1, 2]})
+    m = make_model(cfg, 3, dtype)
+    B = 3
+    x = (torch.from_numpy(synth.normal(8, "x", B * 5 * 24 * 24).reshape(B, 5, 24, 24)) * 10.0).cuda()
+    ctx = synth.synth_context(B, 7, cfg.model.context_dim, 2).cuda()
+    labels = torch.tensor([0, 2, 4]).cuda()
+    try:
+        lib.t2p_debug_set(15, 0)
+        a = m(x, labels, ctx).cpu()
+        lib.t2p_debug_set(15, 1)
+        b = m(x, labels, ctx).cpu()
+    finally:
+        lib.t2p_debug_set(15, 1)
+    assert torch.isfinite(b).all()
+    err = rel_l2(b, a)
+    print(f"thin head conv vs GEMM head conv ({dtype}): rel-L2 = {err:.3e}")
+    assert err < 5e-6      # (bit-identical in practice: same K order, fp32 accumulation)

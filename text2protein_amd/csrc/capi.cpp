@@ -369,6 +369,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 12) { set_gemm_midsplit(value != 0); return T2P_OK; }
   if (key == 13) { g_gn_small = value != 0; return T2P_OK; }
   if (key == 14) { g_lowp_residual = value != 0; return T2P_OK; }
+  if (key == 15) { set_gemm_thin_conv(value != 0); return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) set_gemm_debug(value);
   else if (key == 2) set_gemm_geom(value);

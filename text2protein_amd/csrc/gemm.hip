@@ -1372,6 +1372,108 @@ static int launch_tile(const GemmParams& p, hipStream_t stream) {
   return launch_t<TC, AF32, 128, 128>(p, stream);
 }
 
+// ---- thin-output 3x3 convolution: the network head (nf -> 5 or 8 channels, NCHW fp32 x row scale) ----------
+// As a GEMM this layer has N = 5: the 64-wide tile of the register-staged kernel spends 92 % of its MFMAs on
+// padding and re-reads every input pixel nine times from L2 (426 us at cfg2 against a ~55 us HBM bound).  Here
+// a workgroup owns an 8 x 16 pixel tile: the 10 x 18 halo of 16-bit input pixels is staged once in LDS (chunk
+// index XOR pixel index: conflict-free 16-byte fragment reads), the <= 8 weight rows too, and each wavefront
+// runs v_mfma_f32_16x16x32 on two rows of 16 pixels with the 16 MFMA columns holding the output channels.
+struct ThinConvArgs {
+  const void* x; const void* w; const float* bias; const float* row_scale; float* out;
+  int B, H, W, Cin, Cout;
+  long ldw;
+};
+
+template <typename TC, int CH>   // CH: channels staged per pass (32, 64 or 128)
+__global__ __launch_bounds__(512) void thin_conv_kernel(const ThinConvArgs a) {
+  constexpr int TH = 8, TW = 16, WP = TW + 2, NPIX = (TH + 2) * WP;
+  constexpr int cb = CH * 2, nchunk = CH / 8;               // bytes / 16-byte chunks per staged pixel
+  constexpr int wrow = 9 * cb + 16;                         // padded weight row: lanes of a fragment read hit distinct banks
+  constexpr int sw = (nchunk < 8 ? nchunk : 8) - 1;         // swizzle mask: stays inside the pixel's own chunks
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* halo = smem;
+  unsigned char* wl = smem + NPIX * cb;
+  const int tid = threadIdx.x;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+  const int x0 = tx * TW, y0 = ty * TH;
+  const TC* xb = (const TC*)a.x + (long)b * a.H * a.W * a.Cin;
+  const int wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;   // wave = pixel row of the tile
+  const bool colv = r < a.Cout;                             // MFMA column = output channel
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < a.Cin; c0 += CH) {                  // channel passes: 58 KiB of LDS at CH = 128 -> two blocks per CU
+    if (c0) __syncthreads();                                // the previous pass is no longer read
+    for (int i = tid; i < NPIX * nchunk; i += 512) {
+      const int P = i / nchunk, j = i - P * nchunk;
+      const int gy = y0 + P / WP - 1, gx = x0 + P % WP - 1;
+      u32x4_t v = {0u, 0u, 0u, 0u};                         // zero padding outside the map
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *(const u32x4_t*)(xb + ((long)gy * a.W + gx) * a.Cin + c0 + j * 8);
+      *(u32x4_t*)(halo + P * cb + (((j & ~sw) | ((j ^ P) & sw)) << 4)) = v;
+    }
+    for (int i = tid; i < a.Cout * 9 * nchunk; i += 512) {
+      const int co = i / (9 * nchunk), k = i - co * 9 * nchunk, tap = k / nchunk, j = k - tap * nchunk;
+      *(u32x4_t*)(wl + co * wrow + k * 16) = *(const u32x4_t*)((const TC*)a.w + (long)co * a.ldw + (long)tap * a.Cin + c0 + j * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap % 3;
+      const int P = (wave + dy) * WP + r + dx;
+      u32x4_t af[CH / 32], bf[CH / 32];                     // one tap's fragments in flight before its MFMAs (<= 128 VGPRs
+#pragma unroll                                               //  in total: two 512-thread blocks per CU)
+      for (int kc = 0; kc < CH / 32; ++kc) {
+        const int j = kc * 4 + g;
+        af[kc] = *(const u32x4_t*)(halo + P * cb + (((j & ~sw) | ((j ^ P) & sw)) << 4));
+        bf[kc] = (u32x4_t){0u, 0u, 0u, 0u};
+        if (colv) bf[kc] = *(const u32x4_t*)(wl + r * wrow + (tap * nchunk + j) * 16);
+      }
+#pragma unroll
+      for (int kc = 0; kc < CH / 32; ++kc) Mma16<TC>::run(af[kc], bf[kc], acc);
+    }
+  }
+  if (!colv) return;
+  // 16x16 accumulator: column = lane & 15 (channel), row = (lane >> 4) * 4 + register (pixel of the row)
+  const int y = y0 + wave;
+  if (y >= a.H) return;
+  const float bias = a.bias ? a.bias[r] : 0.f, sc = a.row_scale ? a.row_scale[b] : 1.f;
+  float* o = a.out + (((long)b * a.Cout + r) * a.H + y) * a.W;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int x = x0 + g * 4 + v;
+    if (x < a.W) o[x] = (acc[v] + bias) * sc;
+  }
+}
+
+static bool g_thin_conv = true;
+void set_gemm_thin_conv(bool on) { g_thin_conv = on; }
+
+// true when launch_gemm(p) will take the thin-output kernel
+static bool thin_conv_eligible(const GemmParams& p) {
+  if (p.dtype == DT_F32 || p.a_f32 || p.taps != 9 || p.a_up || !p.c_nchw || !p.c_f32) return false;
+  if (p.A1 || p.R || p.bias_m || p.bias_bn || p.nz0 * p.nz1 != 1 || p.alpha != 1.f || p.geglu) return false;
+  if (p.N > 8 || (p.C0 != 32 && p.C0 != 64 && p.C0 != 128 && p.C0 != 256) || p.lda0 != p.C0) return false;
+  return p.rows_per_batch == p.H * p.W && p.M % (p.H * p.W) == 0;
+}
+
+template <typename TC, int CH>
+static int launch_thin_conv_ch(const ThinConvArgs& a, hipStream_t stream) {
+  constexpr int smem = 180 * CH * 2 + 8 * (9 * CH * 2 + 16);
+  const int tiles = ((a.W + 15) / 16) * ((a.H + 7) / 8);
+  hipLaunchKernelGGL((thin_conv_kernel<TC, CH>), dim3((unsigned)((long)a.B * tiles)), dim3(512), smem, stream, a);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+template <typename TC>
+static int launch_thin_conv(const GemmParams& p, hipStream_t stream) {
+  ThinConvArgs a;
+  a.x = p.A0; a.w = p.Bw; a.bias = p.bias_n; a.row_scale = p.row_scale; a.out = (float*)p.C;
+  a.B = p.M / (p.H * p.W); a.H = p.H; a.W = p.W; a.Cin = p.C0; a.Cout = p.N; a.ldw = p.ldb;
+  if (p.C0 == 32) return launch_thin_conv_ch<TC, 32>(a, stream);
+  if (p.C0 == 64) return launch_thin_conv_ch<TC, 64>(a, stream);
+  return launch_thin_conv_ch<TC, 128>(a, stream);           // 128 or 256 channels: one or two passes
+}
+
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
   const int vec = p.dtype == DT_F32 ? 4 : 8;
   const int Ctot = p.C0 + p.C1;
@@ -1401,6 +1503,22 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
   T2P_REQUIRE(((uintptr_t)p.A0 % 16) == 0 && ((uintptr_t)p.Bw % 16) == 0 && ((uintptr_t)p.A1 % 16) == 0,
               "operands must be 16-byte aligned");
   T2P_REQUIRE((long)(p.M + 127) / 128 < 65536, "M too large for grid.y");
+  if (g_thin_conv && thin_conv_eligible(p)) {
+    // the head convolution: timed as "conv on the register-staged kernel" by the profile hooks' kind 2
+    ProfRec rec;
+    if (g_prof_on) {
+      T2P_HIP_CHECK(hipEventCreate(&rec.a));
+      T2P_HIP_CHECK(hipEventCreate(&rec.b));
+      rec.flops = 2.0 * p.M * p.N * 9.0 * p.C0; rec.kind = 2; rec.name = nullptr; rec.bytes = 0;
+      T2P_HIP_CHECK(hipEventRecord(rec.a, stream));
+    }
+    const int rc = p.dtype == DT_BF16 ? launch_thin_conv<bf16_t>(p, stream) : launch_thin_conv<f16_t>(p, stream);
+    if (g_prof_on) {
+      T2P_HIP_CHECK(hipEventRecord(rec.b, stream));
+      g_prof.push_back(rec);
+    }
+    return rc;
+  }
   if (dma_eligible(p)) return p.dtype == DT_BF16 ? launch_dma<bf16_t>(p, stream) : launch_dma<f16_t>(p, stream);
   switch (p.dtype) {
     case DT_F32: return launch_tile<float, true>(p, stream);
