@@ -153,29 +153,37 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const FlashArgs a) {
         AMma<TC>::run(kf, qf[s], sacc);
       }
       // ---- online softmax: this lane = query lr, registers = keys (v&3) + 8 (v>>2) + 4 lh ----
-      float mx = -INFINITY;
+      // VALU diet (the loop is VALU-bound, not MFMA-bound): keys are masked only in the ragged last
+      // sub-tile, the maximum is taken on the raw scores (scale > 0), scale and shift are one FMA in
+      // front of exp2, and the accumulators are rescaled only when some query's running maximum moved.
+      if (kbase + 32 > a.nk) {                                    // wave-uniform
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int key = kbase + (v & 3) + 8 * (v >> 2) + 4 * lh;
-        sacc[v] = key < a.nk ? sacc[v] * a.scale_log2e : -INFINITY;
-        mx = fmaxf(mx, sacc[v]);
+        for (int v = 0; v < 16; ++v) {
+          const int key = kbase + (v & 3) + 8 * (v >> 2) + 4 * lh;
+          if (key >= a.nk) sacc[v] = -INFINITY;                   // padding rows may hold anything (NaN included)
+        }
       }
+      float mx = sacc[0];
+#pragma unroll
+      for (int v = 1; v < 16; ++v) mx = fmaxf(mx, sacc[v]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m, mx);                           // finite: every sub-tile entered has a valid key
+      const float m_new = fmaxf(m, mx * a.scale_log2e);           // finite: every sub-tile entered has a valid key
       const float alpha = __builtin_amdgcn_exp2f(m - m_new);      // exp2(-inf) = 0 on the first tile
       float rs = 0.f;
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        sacc[v] = __builtin_amdgcn_exp2f(sacc[v] - m_new);
+        sacc[v] = __builtin_amdgcn_exp2f(fmaf(sacc[v], a.scale_log2e, -m_new));
         rs += sacc[v];
       }
       rs += __shfl_xor(rs, 32, 64);
       l = l * alpha + rs;
       m = m_new;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {       // wave-uniform: usually false after the first tiles
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt)
+        for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) o[tt][v] *= alpha;
+          for (int v = 0; v < 16; ++v) o[tt][v] *= alpha;
+      }
       // ---- O^T += V^T P^T: P registers 8 ks .. 8 ks + 7 are the B fragment of k-step ks --------
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -240,6 +248,7 @@ int launch_attention_flash(int dtype, const void* q, long ldq, const void* k, lo
                            void* out, int B, int heads, int nq, int nk, int d, float scale, hipStream_t s) {
   T2P_REQUIRE(attention_flash_eligible(dtype, d, ldq, ldk, ldvt, (long)heads * d), "flash attention: unsupported shape");
   T2P_REQUIRE(q && k && vt && out && B > 0 && heads > 0 && nq > 0 && nk > 0, "flash attention arguments");
+  T2P_REQUIRE(scale > 0.f, "flash attention: the running maximum is taken on unscaled scores (scale must be positive)");
   T2P_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 8) == 0,
               "flash attention: operands must be 16-byte aligned");
   FlashArgs a;
