@@ -112,3 +112,33 @@ def test_midsize_splitk_plan_matches_unsplit(full):
     print(f"vs exact-f32: 128x128 plan {ea:.3e}, 256x256 split-K plan {eb:.3e}; between plans {eab:.3e}")
     assert eab > 0.0                      # a different plan really ran
     assert ea < 2e-3 and eb < 2e-3 and abs(ea - eb) < 0.2 * ea and eab < ea
+
+
+def test_large_config_score_properties():
+    """BASELINE configs[3]: test_config_large.yml at L=256 (863.3 M parameters, 3 res-blocks per level, channel
+    multiplier 4 at the lowest level: AttnBlockpp runs single-head attention with d up to 1024).  The oracle is
+    far too slow here; checked: finite, bitwise reproducible, f16 against the exact-f32 engine, and independence
+    of a sample from the rest of its batch."""
+    from text2protein_amd import synth
+    from text2protein_amd.arch import param_specs
+    from text2protein_amd.config import load_config
+    cfg = load_config(os.path.join(ROOT, "configs", "test_config_large.yml"), **{"data.max_res_num": 256, "model.num_scales": 1000})
+    cfg.device = "cuda:0"
+    assert abs(sum(int(torch.tensor(s.shape).prod()) for s in param_specs(cfg)) / 1e6 - 863.3) < 0.1
+    sd = synth.synth_state_dict(cfg, 0)
+    B, T = 2, 64
+    ctx = synth.synth_context(B, T, cfg.model.context_dim, 4).cuda()
+    x = (torch.from_numpy(synth.normal(9, "x", B * 5 * 256 * 256).reshape(B, 5, 256, 256)) * 20.0).cuda()
+    labels = torch.tensor([100, 900]).cuda()
+    m32 = _model(cfg, sd, "f32")
+    ref = m32(x, labels, ctx).cpu()
+    one = m32(x[1:2], labels[1:2], ctx[1:2]).cpu()
+    del m32
+    assert torch.isfinite(ref).all() and rel_l2(one, ref[1:2]) < 1e-5
+    m16 = _model(cfg, sd, "f16")
+    a = m16(x, labels, ctx).cpu()
+    b = m16(x, labels, ctx).cpu()
+    assert torch.equal(a, b)
+    err = rel_l2(a, ref)
+    print(f"large config (L=256): f16 vs exact-f32 score rel-L2 = {err:.3e}")
+    assert err < 2e-3
