@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the reverse-diffusion sampling path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Under `python -m torch.distributed.run --nproc-per-node N ...` the ranks come from
+the environment; started directly, this script first starts N fresh child processes of itself (before it touches
+the GPU, text2protein_amd/distributed.py:launch_local) and relays rank 0's JSON line.
 
 Workload (BASELINE.json configs[1], SURVEY.md 8(d) "cfg2"): configs/test_config.yml with
 data.max_res_num = 128 and model.num_scales = 1000, 32 chains per GPU, 512 text tokens of width
@@ -52,8 +56,10 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("T2P_GRAPH", "0")),
                     help="replay each PC step from a captured hipGraph instead of launching its kernels one by one")
-    ap.add_argument("--gemm-geom", type=int, default=int(os.environ.get("T2P_GEMM_GEOM", "0")),
-                    help="development: 0 auto, 1 force 256x128x3, 2 force 128x128x2 LDS-DMA GEMM geometry")
+    ap.add_argument("--plan", default="", help="A/B measurements: 'key=value,...' plan switches of t2p_debug_set "
+                    "(include/t2p.h: tile geometry, split-K, individual fusions; all produce correct results)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 engine's line (rank 0, N = 1)")
+    ap.add_argument("--f32-steps", type=int, default=2)
     return ap.parse_args()
 
 
@@ -81,26 +87,20 @@ def cpu_baseline(cfg, sd, ctx_cpu, n_scales):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    from text2protein_amd import distributed as D            # imports torch; does not touch the GPU
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started directly with --gpus N: N fresh children, one rank per GPU; this process never initialises HIP
+        sys.exit(D.launch_local(args.gpus, [os.path.abspath(__file__), *sys.argv[1:]]))
+    rank, world, local_rank = D.env_rank_world()
+    args.gpus = world
     # rehearsal on a one-GPU box: T2P_FORCE_DEVICE=0 T2P_DIST_BACKEND=gloo put every rank on one card
     dev_index = int(os.environ.get("T2P_FORCE_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("T2P_DIST_BACKEND", "nccl")  # "nccl" is RCCL over xGMI on ROCm
-        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    dist = D.init_process_group(dev)                         # "nccl" = RCCL over xGMI on ROCm; None at N = 1
 
     from text2protein_amd import sampling, sde_lib, synth
-    from text2protein_amd._lib import check, load
+    from text2protein_amd._lib import check, load, set_plan_switches
     from text2protein_amd.config import load_config
     from text2protein_amd.model import HipScoreModel
 
@@ -111,11 +111,7 @@ def main():
     N = cfg.model.num_scales
     C_, L = cfg.data.num_channels, cfg.data.max_res_num
 
-    if args.gemm_geom:
-        check(load().t2p_debug_set(2, args.gemm_geom))
-    for key, env in ((3, "T2P_SPLITK"), (4, "T2P_RAW_COPIES"), (5, "T2P_FLASH"), (6, "T2P_FUSE_GN"), (7, "T2P_FUSE_GEGLU"), (8, "T2P_GEMM_RING"), (9, "T2P_LOWP_H1")):      # development A/B switches
-        if env in os.environ:
-            check(load().t2p_debug_set(key, int(os.environ[env])))
+    set_plan_switches(args.plan)
     t_setup = time.perf_counter()
     sd = synth.synth_state_dict(cfg, seed=0)                 # same weights on every rank (replicated model)
     model = HipScoreModel(cfg, dtype=args.dtype, device=str(dev))
@@ -125,8 +121,8 @@ def main():
     model.set_context(ctx)                                   # one-off K/V projection of the frozen text
     sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=N)
     stepper = sampling.PCStepper(model, sde, B, cfg.sampling.snr, cfg.sampling.n_steps_each,
-                                 cfg.sampling.probability_flow, cfg.sampling.noise_removal, 1e-5, seed=rank)
-    x = sampling._device_randn_like(torch.empty(B, C_, L, L, device=dev), 12345 + rank, 0) * sde.prior_scale()
+                                 cfg.sampling.probability_flow, cfg.sampling.noise_removal, 1e-5, seed=D.rank_seed(0, rank))
+    x = sampling._device_randn_like(torch.empty(B, C_, L, L, device=dev), D.rank_seed(12345, rank), 0) * sde.prior_scale()
     if cond_kind:
         from text2protein_amd.conditions import synthetic_condition
         x, mask = sampling.apply_conditions(x, synthetic_condition(cfg, B, cond_kind, dev))
@@ -136,11 +132,6 @@ def main():
     stepper.reset(0)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     side = torch.cuda.Stream(device=dev) if args.graph else None      # stream capture needs a real stream
     run_step = stepper.step
@@ -154,22 +145,22 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         run_step(x, x_mean)
-    gathered = [torch.empty_like(x_mean) for _ in range(world)] if dist is not None else None
-    barrier()
+    if dist is not None:
+        D.gather_samples(x_mean, dist)                       # RCCL communicator set-up is not part of a run
+    # the schedule tables hold N steps: the timed region starts at step 0 of a run and rewinds every N steps
+    stepper.reset(0)
+    D.barrier(dist, dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i and i % N == 0:
+            stepper.reset(0)
         run_step(x, x_mean)
     if side is not None:
         torch.cuda.current_stream().wait_stream(side)
-    if dist is not None:
-        dist.all_gather(gathered, x_mean)                    # the single collective of a run
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    finite = bool(torch.isfinite(x_mean).all().item())
+    gathered = D.gather_samples(x_mean, dist)                # the single collective of a run (no-op at N = 1)
+    D.barrier(dist, dev)
+    dt = D.max_over_ranks(time.perf_counter() - t0, dist, dev)
+    finite = bool(torch.isfinite(gathered).all().item()) and gathered.shape[0] == B * world
 
     ms_per_step = dt / args.steps * 1e3
     total_chains = B * world
@@ -192,6 +183,7 @@ def main():
         # dominant kernel = the LDS-DMA implicit-GEMM 3x3 convolution (gemm_dma_kernel, modes 1/2):
         # every launch of one PC step timed with HIP events on the launch stream
         lib = load()
+        stepper.reset(0)
         check(lib.t2p_profile_begin())
         nprof = 1
         for _ in range(nprof):
@@ -227,6 +219,8 @@ def main():
         out["roofline"] = {
             "bound": "mfma", "kernel": kname,
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+            # not measured in this run: HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
+            "traffic_from_profile": ({"bytes_per_launch": traffic, "file": os.path.relpath(tfile[-1], ROOT)} if traffic else None),
             "launches_per_step": conv_n / nprof, "avg_launch_ms": conv_ms / max(conv_n, 1),
             "algorithmic_gflop_per_launch": conv_fl / max(conv_n, 1) / 1e9,
             "algorithmic_bytes_per_launch": (dom_bytes / dom_n) if dom_n > 0 else None,
@@ -236,6 +230,27 @@ def main():
                            "share_of_step_ms": g_ms / nprof, "frac": (g_fl / (g_ms * 1e-3) / 1e12 / peak) if g_ms > 0 else 0.0},
             "conv_on_v1_kernel": {"launches_per_step": c1_n / nprof, "share_of_step_ms": c1_ms / nprof},
         }
+    if rank == 0 and world == 1 and not args.no_f32 and args.dtype != "f32":
+        # the same workload on the exact-f32 engine (v_mfma_f32_32x32x2_f32: the reference's own arithmetic type),
+        # so that both precisions are on record; a few steps are enough (every step has the same cost)
+        del stepper
+        m32 = HipScoreModel(cfg, dtype="f32", device=str(dev))
+        m32.load_state_dict(sd)
+        m32.set_context(ctx)
+        st32 = sampling.PCStepper(m32, sde, B, cfg.sampling.snr, cfg.sampling.n_steps_each, cfg.sampling.probability_flow,
+                                  cfg.sampling.noise_removal, 1e-5, seed=D.rank_seed(0, rank))
+        st32.reset(0)
+        st32.step(x, x_mean)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.f32_steps):
+            st32.step(x, x_mean)
+        torch.cuda.synchronize()
+        d32 = (time.perf_counter() - t0) / args.f32_steps
+        v32 = B / (N * d32)
+        out["f32"] = {"value": v32, "unit": "samples/s", "ms_per_step": d32 * 1e3, "steps": args.f32_steps,
+                      "mfma_frac_end_to_end": v32 * 2 * N * alg / (MFMA_PEAK_TFLOPS["f32"] * 1e12), "peak": MFMA_PEAK_TFLOPS["f32"]}
+        del st32, m32
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, sd, ctx_cpu, N)
     if dist is not None:

@@ -96,18 +96,32 @@ typedef struct t2p_sampler_config {
   int32_t denoise;           /* sampling.noise_removal                                            */
   double eps;                /* integrate to eps (1e-5 for VE, sampling_6d.py:79)                 */
   int32_t batch;             /* chains held by this process                                       */
-  int32_t global_batch;      /* chains the Langevin batch-mean runs over (>= batch; == batch unless
-                                the caller all-reduces the norm sums itself)                      */
+  int32_t global_batch;      /* chains the Langevin batch-mean runs over (>= batch; > batch needs
+                                t2p_sampler_set_norm_allreduce)                                   */
   uint64_t seed;             /* on-device Philox noise                                            */
 } t2p_sampler_config;
 
 /* g_table: optional host float[N], G_i of step i as the reference computes it in float32
- * (sde_lib.py:237-245); NULL = computed here in double. */
-int t2p_sampler_create(t2p_engine* e, const t2p_sampler_config* cfg, const float* g_table, t2p_sampler** out);
+ * (sde_lib.py:237-245); NULL = computed here in double.
+ * label_table: optional host int32[N], the time label the score network receives at loop step i,
+ * round((T - linspace(T, eps, N)[i]) (N - 1)) in the reference's float32 arithmetic (sampling.py:257,
+ * models/utils.py:159-171); NULL = computed here in double from cfg->eps.  (It equals i only for tiny eps.) */
+int t2p_sampler_create(t2p_engine* e, const t2p_sampler_config* cfg, const float* g_table, const int32_t* label_table,
+                       t2p_sampler** out);
 void t2p_sampler_destroy(t2p_sampler* s);
+/* Seed of the on-device Philox noise of the following steps.  The reference draws fresh torch.randn noise on
+ * every call of pc_sampler; the Python mirror derives one seed per (seed, call index) and sets it here. */
+int t2p_sampler_set_seed(t2p_sampler* s, uint64_t seed);
+/* Global-batch Langevin step size (the reference's DataParallel run takes the norm means over the whole batch,
+ * sampling.py:193-195; cfg.global_batch > cfg.batch): every corrector step writes {sum_b ||grad_b||,
+ * sum_b ||noise_b||} of this process's chains to `device_sums2` (caller-owned device float[2]) and calls
+ * fn(device_sums2, stream, user), which must sum the two floats over all processes in stream order (one RCCL
+ * all_reduce) and return 0.  NULL, NULL, NULL removes the hook. */
+typedef int (*t2p_allreduce_fn)(float* device_sums2, void* stream, void* user);
+int t2p_sampler_set_norm_allreduce(t2p_sampler* s, float* device_sums2, t2p_allreduce_fn fn, void* user);
 /* mask: device uint8 (B,C,L,L), 1 where the chain evolves; x_initial: device fp32; both NULL = unconditional */
 int t2p_sampler_set_condition(t2p_sampler* s, const uint8_t* mask, const float* x_initial);
-/* reset the device step counter to `step` (0 at the start of a run) */
+/* reset the step counter to `step` (0 at the start of a run); a step at index >= N is refused */
 int t2p_sampler_reset(t2p_sampler* s, int step, void* stream);
 /* One PC step at the current step index, in place on x (device fp32 (B,C,L,L)); x_mean receives the
  * predictor's mean.  noise_corrector / noise_predictor: device standard-normal draws to use
@@ -181,10 +195,15 @@ int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int
 /* ---- measurement hooks (bench.py): time every MFMA GEMM launch with HIP events on its stream ----
  * out9 = {LDS-DMA conv3x3: ms, flops, launches; other GEMMs: ...; conv3x3 on the register-staged kernel: ...} since t2p_profile_begin */
 int t2p_profile_begin(void);
-/* development switches: key 0 = enable (1) / disable (0) the LDS-DMA GEMM kernel; key 1 = timing-only
- * ablation mask of that kernel (bits 1..64 produce wrong results; bits 128 / 256 only switch off the
- * staggered DMA issue order of the two wave halves, results unchanged; never set in product code) */
+/* Plan switches for tests and A/B measurements: they select between kernel geometries / fusions that all
+ * produce correct results (key 0 LDS-DMA GEMM on/off, 2 tile geometry, 3 split-K, 4..15 individual fusions;
+ * text2protein_amd/csrc/capi.cpp).  Key 1 is the timing-only ablation mask of the LDS-DMA kernel: its bits
+ * 128 / 256 (DMA issue order, results unchanged) are always accepted, the bits that skip work and so produce
+ * WRONG results exist only in a library built with -DT2P_ABLATION (python -m text2protein_amd.build --ablation)
+ * and are refused (status 1) by the product build. */
 int t2p_debug_set(int key, int value);
+/* 1 when the library was built with -DT2P_ABLATION (never the shipped one) */
+int t2p_built_with_ablation(void);
 int t2p_profile_end(double* out9);
 /* after t2p_profile_end: the 3x3-convolution kernel instantiation with the largest total time in that region --
  * out4 = {ms (main kernel only), flops, launches, algorithmic bytes (inputs, weights, residual and output once each)},

@@ -19,8 +19,10 @@ Differences, all at the edges of the hot path:
   * ``--pdb`` conditions need biotite and are broken in the reference: refused.
   * ``checkpoint`` may be the word ``synthetic`` (hash-generated weights, no file needed).
   * extra flags: --dtype (f32|f16|bf16), --seed, --ids, --num_scales / --max_res_num overrides.
-Under ``python -m torch.distributed.run --nproc-per-node N`` every rank samples ``--batch_size``
-chains on its own GPU and rank 0 gathers them with one RCCL all_gather before writing.
+Under ``python -m torch.distributed.run --nproc-per-node N`` (or with ``--gpus N``, which starts the N ranks
+itself) every rank samples ``--batch_size`` chains on its own GPU and rank 0 gathers them with one RCCL
+all_gather before writing (text2protein_amd/distributed.py).  ``--global_batch_norm`` reproduces the reference's
+multi-GPU (DataParallel) Langevin step size: batch means over all ranks' chains, one 2-float all-reduce per step.
 """
 import argparse
 import os
@@ -61,21 +63,26 @@ def main():
     parser.add_argument("--tokenizer_path", type=str, default=None)
     parser.add_argument("--embed_table", type=str, default=None)
     parser.add_argument("--decode", action="store_true", help="also write decoded_<id>.npz (sampling_rosetta.py:69-96)")
+    parser.add_argument("--gpus", type=int, default=1, help="start this many ranks (one per GPU) when not under torch.distributed.run")
+    parser.add_argument("--global_batch_norm", action="store_true",
+                        help="Langevin batch means over every rank's chains (the reference's DataParallel semantics)")
     args = parser.parse_args()
 
     assert not (args.pdb is not None and args.select_length)
     if args.pdb is not None:
         raise SystemExit("--pdb conditions are outside the sampling hot path (need biotite; see SURVEY.md section 2, row 10)")
 
+    from text2protein_amd import distributed as D
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:      # before anything touches the GPU
+        import sys
+        raise SystemExit(D.launch_local(args.gpus, [os.path.abspath(__file__), *sys.argv[1:]]))
     from text2protein_amd import sampling, sde_lib, synth
     from text2protein_amd.checkpoint import restore_checkpoint
     from text2protein_amd.conditions import get_mask_all_lengths
     from text2protein_amd.config import load_config
     from text2protein_amd.model import HipScoreModel
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local_rank = D.env_rank_world()
     overrides = {}
     if args.num_scales:
         overrides["model.num_scales"] = args.num_scales
@@ -85,11 +92,7 @@ def main():
     device = f"cuda:{local_rank}" if args.device == "cuda" else args.device
     config.device = device
     torch.cuda.set_device(torch.device(device))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+    dist = D.init_process_group(device)
 
     run = Path(args.checkpoint).parent.parent.stem if args.checkpoint != "synthetic" else "synthetic"
     workdir = Path(args.outdir) if args.outdir else Path("sampling", "coords_6d", Path(args.config).stem, run, args.tag)
@@ -115,7 +118,11 @@ def main():
 
     B = args.batch_size
     sampling_shape = (B, config.data.num_channels, config.data.max_res_num, config.data.max_res_num)
-    sampling_fn = sampling.get_sampling_fn(config, sde, sampling_shape, sampling_eps, seed=args.seed * 1000 + rank)
+    kw = {}
+    if args.global_batch_norm and dist is not None:
+        kw = {"global_batch": B * world, "all_reduce": lambda sums: D.allreduce_norm_sums(sums, dist)}
+    # every rank its own noise stream; every iteration of the --n_iter loop a fresh one (call index, sampling.py)
+    sampling_fn = sampling.get_sampling_fn(config, sde, sampling_shape, sampling_eps, seed=D.rank_seed(args.seed, rank), **kw)
 
     caption_ids = None
     if args.captions:
@@ -135,7 +142,7 @@ def main():
             raise SystemExit(f"embedding width {context.shape[-1]} != model.context_dim {config.model.context_dim}")
         del producer
     elif args.context == "synthetic":
-        context = synth.synth_context(B, args.context_tokens, config.model.context_dim, seed=args.seed * 1000 + rank)
+        context = synth.synth_context(B, args.context_tokens, config.model.context_dim, seed=D.rank_seed(args.seed, rank))
     else:
         context = torch.load(args.context, map_location="cpu")
         if context.shape[0] != B:
@@ -152,11 +159,9 @@ def main():
             condition = {}
         sample, n = sampling_fn(score_model, condition=condition, context=context)
         if dist is not None:
-            parts = [torch.empty_like(sample) for _ in range(world)]
-            dist.all_gather(parts, sample.contiguous())
+            sample = D.gather_samples(sample, dist)          # the single data-path collective of a run
             all_ids = [None] * world
             dist.all_gather_object(all_ids, ids)
-            sample = torch.cat(parts, 0)
             out_ids = [i for sub in all_ids for i in sub]
         else:
             out_ids = ids

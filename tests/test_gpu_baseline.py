@@ -1,0 +1,198 @@
+"""Every BASELINE configuration against outputs of the REFERENCE itself (tests/golden/make_golden_full.py):
+
+  * one score evaluation per shipped YAML at its real size (configs[1..4]: test_config L=128, cond_length,
+    cond_length_inpainting (C=8), test_config_large L=256): exact-f32 engine <= 1e-5, f16 engine within the
+    north star's 1e-3; the same fixture samples embedded in a batch of the BENCHMARK's size (32 / 16 chains,
+    up to M = 1 M rows: 32-bit offset arithmetic, tile scheduling) between unrelated filler chains; and under
+    every forced LDS-DMA tile geometry, the 512 x 128 one of cfg3 / cfg5 included;
+  * configs[0] (test_config.yml, B=2, L=64, N=100): the complete 100-step PC run on the reference's noise;
+  * the 1000-step horizon the metric is quoted on: f16 against the exact-f32 engine on identical Philox noise at
+    cfg2 and cfg3 shapes (the 100-step fixture shows f16-vs-f32-engine == f16-vs-reference).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import FULL, CounterNoise, full_inputs, load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+
+F32_TOL = 1e-5
+F16_TOL = 1e-3          # BASELINE.json north_star: "matching CPU reference within 1e-3 rel-L2"
+
+
+def _cfg(stem, **over):
+    from text2protein_amd.config import load_config
+    fname, L, N, B, T, chains = FULL[stem]
+    cfg = load_config(os.path.join(ROOT, "configs", fname), **{"data.max_res_num": L, "model.num_scales": N, **over})
+    cfg.device = "cuda:0"
+    return cfg, B, T, chains
+
+
+def _model(cfg, sd, dtype):
+    from text2protein_amd.model import HipScoreModel
+    m = HipScoreModel(cfg, dtype=dtype)
+    m.load_state_dict(sd)
+    return m
+
+
+def _record(name, value):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, "r02_parity.json")
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data[name] = value
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+
+
+@pytest.fixture(scope="module", params=list(FULL))
+def full(request):
+    from text2protein_amd import synth
+    stem = request.param
+    cfg, B, T, chains = _cfg(stem)
+    g = load_golden("full_" + stem)
+    assert int(g["B"]) == B and int(g["T"]) == T
+    sd = synth.synth_state_dict(cfg, 0)
+    x, labels, ctx = full_inputs(cfg, B, T)
+    return stem, cfg, sd, x.cuda(), labels.cuda(), ctx.cuda(), torch.from_numpy(g["score"]), chains
+
+
+def test_param_table_matches_reference_named_parameters():
+    """arch.param_specs and the engine's own table against the reference's named_parameters() (the order the EMA
+    shadow list follows, models/ema.py:51-64) for the four shipped YAMLs."""
+    from text2protein_amd.arch import param_specs
+    tables = json.load(open(os.path.join(ROOT, "tests", "golden", "param_tables.json")))
+    assert sorted(tables) == sorted(FULL)
+    for stem, t in tables.items():
+        cfg, _, _, _ = _cfg(stem)
+        want = [(n, tuple(s)) for n, s in t["named_parameters"]]
+        assert [(s.name, tuple(s.shape)) for s in param_specs(cfg)] == want
+        from text2protein_amd.model import HipScoreModel
+        m = HipScoreModel(cfg, dtype="f16")
+        assert m.engine_param_table() == want
+        assert sum(int(np.prod(s)) for _, s in want) == t["n_params"]
+
+
+def test_full_size_score_vs_reference(full):
+    stem, cfg, sd, x, labels, ctx, want, _ = full
+    m32 = _model(cfg, sd, "f32")
+    e32 = rel_l2(m32(x, labels, ctx).cpu(), want)
+    del m32
+    m16 = _model(cfg, sd, "f16")
+    e16 = rel_l2(m16(x, labels, ctx).cpu(), want)
+    print(f"{stem}: one score evaluation vs the reference: f32 {e32:.3e}, f16 {e16:.3e}")
+    _record(f"score_{stem}", {"f32": e32, "f16": e16, "L": cfg.data.max_res_num, "batch": int(x.shape[0])})
+    assert e32 < F32_TOL
+    assert e16 < F16_TOL
+
+
+def test_benchmark_batch_holds_the_reference_samples(full):
+    """The fixture's samples inside a batch of the benchmark's size (first and last slots), every other slot an
+    unrelated chain with its own text and time label: each must still come out as the reference computed it."""
+    from text2protein_amd import synth
+    stem, cfg, sd, x, labels, ctx, want, chains = full
+    B0, T = x.shape[0], ctx.shape[1]
+    xs = torch.from_numpy(synth.normal(77, "filler_x", chains * x[0].numel()).reshape(chains, *x.shape[1:])).cuda() * 20.0
+    cs = synth.synth_context(chains, T, cfg.model.context_dim, 78).cuda()
+    ls = (torch.arange(chains, device="cuda") * 37 + 11) % cfg.model.num_scales
+    slots = [0, chains - 1][:B0] if B0 > 1 else [chains - 1]
+    for i, s in enumerate(slots):
+        xs[s], cs[s], ls[s] = x[i], ctx[i], labels[i]
+    m16 = _model(cfg, sd, "f16")
+    out = m16(xs, ls, cs)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    for i, s in enumerate(slots):
+        e = rel_l2(out[s].cpu(), want[i])
+        print(f"{stem}: sample {i} in slot {s} of {chains} chains: f16 vs reference {e:.3e}")
+        _record(f"score_{stem}_batch{chains}_slot{s}", e)
+        assert e < F16_TOL
+
+
+@pytest.mark.parametrize("geom", [1, 2, 3, 4])
+def test_forced_tile_geometries_on_cfg3(geom):
+    """cfg3 / cfg5 run their wide maps on the 512 x 128 geometry (plan value 4), which no small shape selects by
+    itself: every forced geometry of the LDS-DMA GEMM must reproduce the reference's score."""
+    from text2protein_amd import _lib, synth
+    stem = "cond_length"
+    cfg, B, T, _ = _cfg(stem)
+    g = load_golden("full_" + stem)
+    sd = synth.synth_state_dict(cfg, 0)
+    x, labels, ctx = full_inputs(cfg, B, T)
+    lib = _lib.load()
+    m16 = _model(cfg, sd, "f16")
+    try:
+        _lib.check(lib.t2p_debug_set(2, geom))
+        lib.t2p_profile_begin()
+        out = m16(x.cuda(), labels.cuda(), ctx.cuda()).cpu()
+        o9 = (__import__("ctypes").c_double * 9)()
+        lib.t2p_profile_end(o9)
+        name = __import__("ctypes").create_string_buffer(256)
+        dom = (__import__("ctypes").c_double * 4)()
+        lib.t2p_profile_dominant(dom, name, 256)
+    finally:
+        lib.t2p_debug_set(2, 0)
+    e = rel_l2(out, g["score"])
+    kname = name.value.decode()
+    print(f"geometry {geom}: dominant conv kernel {kname}: f16 vs reference {e:.3e}")
+    want = {1: "256, 128", 2: "128, 128", 3: "256, 256", 4: "512, 128"}[geom]
+    assert want in kname
+    _record(f"score_cond_length_geom{geom}", {"kernel": kname, "f16": e})
+    assert e < F16_TOL
+
+
+def test_cfg1_hundred_step_run_vs_reference():
+    """BASELINE configs[0]: the reference sampler's complete run (B=2, L=64, N=100) on counter-based noise."""
+    from text2protein_amd import sampling, sde_lib, synth
+    from text2protein_amd.config import load_config
+    g = load_golden("cfg1_run100")
+    B, L, N, T = int(g["B"]), int(g["L"]), int(g["N"]), int(g["T"])
+    cfg = load_config(os.path.join(ROOT, "configs", "test_config.yml"), **{"data.max_res_num": L, "model.num_scales": N})
+    cfg.device = "cuda:0"
+    sd = synth.synth_state_dict(cfg, 0)
+    ctx = synth.synth_context(B, T, cfg.model.context_dim, int(g["context_seed"]))
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=N)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, cfg.data.num_channels, L, L), 1e-5)
+    res = {}
+    for dt, tol in (("f32", F32_TOL), ("f16", F16_TOL)):
+        m = _model(cfg, sd, dt)
+        noise = CounterNoise(int(g["noise_seed"]))
+        out, nfe = fn(m, context=ctx, noise_fn=noise.draw)
+        torch.cuda.synchronize()
+        assert nfe == int(g["nfe"]) and noise.k == 1 + 2 * N
+        res[dt] = rel_l2(out.cpu(), g["sample"])
+        print(f"configs[0], 100 PC steps: {dt} final sample vs the reference run {res[dt]:.3e}")
+        del m
+    _record("cfg1_run100", res)
+    assert res["f32"] < F32_TOL and res["f16"] < F16_TOL
+
+
+@pytest.mark.parametrize("stem", ["test_config", "cond_length"])
+def test_thousand_step_f16_within_tolerance(stem):
+    """The horizon the metric is quoted on: a complete 1000-step run at the cfg2 / cfg3 shape (2 chains), f16
+    engine against the exact-f32 engine on identical on-device Philox noise."""
+    from text2protein_amd import sampling, sde_lib, synth
+    from text2protein_amd.conditions import synthetic_condition
+    cfg, _, T, _ = _cfg(stem)
+    B, C, L, N = 2, cfg.data.num_channels, cfg.data.max_res_num, cfg.model.num_scales
+    sd = synth.synth_state_dict(cfg, 0)
+    ctx = synth.synth_context(B, T, cfg.model.context_dim, 9).cuda()
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=N)
+    cond = synthetic_condition(cfg, B, "length", "cuda:0", length=100) if "length" in stem else None
+    outs = {}
+    for dt in ("f32", "f16"):
+        m = _model(cfg, sd, dt)
+        fn = sampling.get_sampling_fn(cfg, sde, (B, C, L, L), 1e-5, seed=4242)
+        outs[dt], nfe = fn(m, condition=cond, context=ctx, call_index=0)
+        torch.cuda.synchronize()
+        assert nfe == 2 * N and torch.isfinite(outs[dt]).all()
+        outs[dt] = outs[dt].cpu()
+        del m, fn
+    e = rel_l2(outs["f16"], outs["f32"])
+    print(f"{stem}: 1000 PC steps, f16 vs exact-f32 engine, final sample rel-L2 = {e:.3e}")
+    _record(f"run1000_{stem}", {"f16_vs_f32_engine": e, "chains": B, "L": L, "N": N})
+    assert e < F16_TOL

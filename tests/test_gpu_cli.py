@@ -44,6 +44,36 @@ def test_cli_roundtrip(tmp_path):
     assert torch.isfinite(t).all()
 
 
+def test_reference_written_checkpoint_restores_the_ema_weights():
+    """tests/golden/tiny_checkpoint.pth was written by the reference's own save_checkpoint (DataParallel keys, Adam
+    state, ExponentialMovingAverage.state_dict() whose shadow differs from the live weights); the expected score is
+    what the reference computes after restore_checkpoint + ema.copy_to (sampling_6d.py:64-73)."""
+    import numpy as np
+    from helpers import GOLDEN, cfg_ckpt, load_golden, rel_l2
+    from text2protein_amd import synth
+    from text2protein_amd.checkpoint import restore_checkpoint
+    from text2protein_amd.model import HipScoreModel
+    g = load_golden("tiny_checkpoint_expected")
+    cfg = cfg_ckpt()
+    cfg.device = "cuda"
+    x, labels, ctx = (torch.from_numpy(g[k]).cuda() for k in ("x", "labels", "context"))
+    m = HipScoreModel(cfg, dtype="f32")
+    step = restore_checkpoint(os.path.join(GOLDEN, "tiny_checkpoint.pth"), m, cfg)
+    got = m(x, labels, ctx).cpu()
+    assert step == int(g["step"]) == 1234
+    e = rel_l2(got, g["score"])
+    print(f"checkpoint-restored (EMA) score vs the reference's: {e:.3e}")
+    assert e < 1e-5
+    assert rel_l2(got, g["score_live"]) > 1e-2                      # not the live (non-EMA) weights
+    direct = HipScoreModel(cfg, dtype="f32")
+    direct.load_state_dict(synth.synth_state_dict(cfg, int(g["ema_seed"])))
+    assert torch.equal(direct(x, labels, ctx).cpu(), got)           # == loading the EMA tensors by name
+    live = HipScoreModel(cfg, dtype="f32")
+    restore_checkpoint(os.path.join(GOLDEN, "tiny_checkpoint.pth"), live, cfg, use_ema=False)
+    assert rel_l2(live(x, labels, ctx).cpu(), g["score_live"]) < 1e-5
+    assert np.isfinite(g["score"]).all()
+
+
 def test_cli_captions_and_decode(tmp_path, tiny_tokenizer_dir):
     """captions -> local tokenizer + embedding table -> context (sampling_6d.py:121-137) and --decode
     (sampling_rosetta.py:69-96): the decoded maps equal the oracle's decode of the pickled sample."""

@@ -74,8 +74,8 @@ def test_full_size_sampler_invariants(full):
     B = 4
     fn = sampling.get_sampling_fn(cfg, sde, (B, 5, 128, 128), 1e-5, seed=11)
     cond = synthetic_condition(cfg, B, "length+inpainting", "cuda:0", length=100)
-    out, nfe = fn(m, condition=cond, context=ctx, n_iter=3)
-    out2, _ = fn(m, condition=cond, context=ctx, n_iter=3)
+    out, nfe = fn(m, condition=cond, context=ctx, n_iter=3, call_index=0)
+    out2, _ = fn(m, condition=cond, context=ctx, n_iter=3, call_index=0)
     torch.cuda.synchronize()
     assert nfe == 2000 and torch.isfinite(out).all()
     assert torch.equal(out, out2)                               # counter-based device noise: reproducible

@@ -67,17 +67,144 @@ def test_sampler_16bit(dtype):
     assert err < SAMPLE_TOL[dtype]
 
 
-def test_device_noise_run_is_reproducible_and_finite():
-    g, model, fn, cond, _ = _setup("length", "f32", seed=7)
+@pytest.mark.parametrize("route", ["fused", "classes"])
+def test_device_noise_fresh_per_call_and_reproducible(route):
+    """Like the reference (fresh torch.randn draws on every call of pc_sampler), consecutive calls of one sampling
+    function give different samples; a fixed (seed, call index) reproduces bit for bit, also from a new sampler."""
+    kw = dict(seed=7, force_classes=(route == "classes"))
+    g, model, fn, cond, _ = _setup("length", "f32", **kw)
     ctx = torch.from_numpy(g["context"])
     a, _ = fn(model, condition=cond, context=ctx)
     b, _ = fn(model, condition=cond, context=ctx)
+    a0, _ = fn(model, condition=cond, context=ctx, call_index=0)
+    b1, _ = fn(model, condition=cond, context=ctx, call_index=1)
     torch.cuda.synchronize()
-    assert torch.isfinite(a).all()
-    assert torch.equal(a, b)
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert not torch.equal(a, b)
+    assert torch.equal(a, a0) and torch.equal(b, b1)
+    _, _, fn2, _, _ = _setup("length", "f32", **kw)
+    c, _ = fn2(model, condition=cond, context=ctx)
+    assert torch.equal(a, c)
     m = torch.from_numpy(g["cond_length"]).cuda()
     assert torch.equal(a[:, -1], m.float())
     assert float((a[:, :-1] * (~m).unsqueeze(1)).abs().max()) == 0.0
+
+
+def test_ss_condition_matches_reference_run():
+    """`ss` condition (sampling.py:268-270): channels 4:7 are given and frozen; C = 8, with a length mask."""
+    from helpers import cfg_ss
+    from text2protein_amd import synth, sde_lib, sampling
+    from text2protein_amd.model import HipScoreModel
+    g = load_golden("tiny_sampler_ss")
+    cfg = cfg_ss()
+    cfg.device = "cuda"
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=cfg.model.num_scales)
+    shape = (2, 8, cfg.data.max_res_num, cfg.data.max_res_num)
+    ss = torch.from_numpy(g["cond_ss"])
+    for route in ("fused", "classes"):
+        model = HipScoreModel(cfg, dtype="f32")
+        model.load_state_dict(synth.synth_state_dict(cfg, int(g["seed"])))
+        fn = sampling.get_sampling_fn(cfg, sde, shape, 1e-5, force_classes=(route == "classes"))
+        it = iter([torch.from_numpy(z) for z in g["noise"]])
+        cond = {"length": torch.from_numpy(g["cond_length"]), "ss": ss.clone()}
+        out, nfe = fn(model, condition=cond, context=torch.from_numpy(g["context"]), noise_fn=lambda shp: next(it))
+        torch.cuda.synchronize()
+        err = rel_l2(out.cpu(), g["sample"])
+        print(f"ss/{route}: final sample rel-L2 vs reference = {err:.3e}")
+        assert nfe == int(g["nfe"]) and err < SAMPLE_TOL["f32"]
+        assert torch.equal(out[:, 4:7].cpu(), ss)                # the given channels come back untouched
+
+
+def test_fused_route_uses_the_reference_time_labels_at_large_eps():
+    """get_pc_sampler's own default eps = 1e-3: the label round((T - t_i)(N - 1)) differs from the loop index for
+    about half of the steps (N = 1000: 499 of them; here N = 200).  Fused and class routes must agree, and the
+    label table is the reference's."""
+    from text2protein_amd import synth, sde_lib, sampling
+    from text2protein_amd.config import tiny_config
+    from text2protein_amd.model import HipScoreModel
+    N = 200
+    cfg = tiny_config(**{"model.num_scales": N})
+    cfg.device = "cuda"
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=N)
+    lab = sde.label_table(1e-3)
+    assert int((lab != torch.arange(N)).sum()) > N // 4 and int(lab[-1]) == N - 2      # eps = 1e-3: the last label is N - 2
+    assert torch.equal(sde.label_table(1e-5), torch.arange(N, dtype=torch.int32))     # the CLI's eps: label == index
+    t = load_golden("tables")
+    sde1k = sde_lib.VESDE(sigma_min=0.01, sigma_max=100.0, N=1000)
+    assert torch.equal(sde1k.label_table(1e-5).long(), torch.from_numpy(t["labels_1000"]))
+    model = HipScoreModel(cfg, dtype="f32")
+    model.load_state_dict(synth.synth_state_dict(cfg, 0))
+    ctx = synth.synth_context(2, 3, cfg.model.context_dim, 0)
+    g = torch.Generator().manual_seed(5)
+    draws = [torch.randn(2, 5, 16, 16, generator=g) for _ in range(1 + 2 * N)]
+    outs = []
+    for force in (False, True):
+        fn = sampling.get_sampling_fn(cfg, sde, (2, 5, 16, 16), 1e-3, force_classes=force)
+        it = iter(draws)
+        out, _ = fn(model, context=ctx, noise_fn=lambda s: next(it))
+        outs.append(out.cpu())
+    err = rel_l2(outs[0], outs[1])
+    print(f"eps = 1e-3, N = {N}: fused vs classes rel-L2 = {err:.3e}")
+    assert err < 1e-5
+
+
+def test_step_beyond_the_schedule_is_refused():
+    """The schedule tables hold N entries: the (N + 1)-th step without a reset is an error, not a read past them."""
+    from text2protein_amd import synth, sde_lib, sampling
+    from text2protein_amd._lib import T2PError
+    from text2protein_amd.model import HipScoreModel
+    cfg = cfg_tiny()
+    cfg.device = "cuda"
+    model = HipScoreModel(cfg, dtype="f32")
+    model.load_state_dict(synth.synth_state_dict(cfg, 0))
+    model.set_context(synth.synth_context(2, 3, cfg.model.context_dim, 0).cuda())
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=cfg.model.num_scales)
+    st = sampling.PCStepper(model, sde, 2, cfg.sampling.snr, seed=5)
+    x = torch.randn(2, 5, 16, 16, device="cuda") * 100.0
+    xm = torch.empty_like(x)
+    st.reset(0)
+    for _ in range(sde.N):
+        st.step(x, xm)
+    with pytest.raises(T2PError, match="beyond sde.N"):
+        st.step(x, xm)
+    st.reset(0)
+    st.step(x, xm)
+    torch.cuda.synchronize()
+    assert torch.isfinite(x).all()
+
+
+def test_global_batch_norm_two_ranks_equal_one_process(tmp_path):
+    """SURVEY 8(e) option B: two processes with one chain each and the norm all-reduce hook reproduce a single
+    process holding both chains (the reference's DataParallel semantics, sampling.py:193-195)."""
+    import os
+    import sys
+    from text2protein_amd import distributed as D
+    from text2protein_amd import synth, sde_lib, sampling
+    from text2protein_amd.model import HipScoreModel
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rc = D.launch_local(2, [os.path.join(root, "tests", "dist_worker.py"), "gpu_global_batch", str(tmp_path)],
+                        env_extra={"T2P_FORCE_DEVICE": "0", "T2P_DIST_BACKEND": "gloo"}, timeout=600)
+    assert rc == 0
+    got = torch.cat([torch.load(tmp_path / f"rank{r}.pt") for r in range(2)], 0)
+    cfg = cfg_tiny()
+    cfg.device = "cuda"
+    model = HipScoreModel(cfg, dtype="f32")
+    model.load_state_dict(synth.synth_state_dict(cfg, 0))
+    ctx = synth.synth_context(2, 3, cfg.model.context_dim, 0)
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=cfg.model.num_scales)
+    g = torch.Generator().manual_seed(31)
+    draws = [torch.randn(2, 5, 16, 16, generator=g) for _ in range(1 + 2 * sde.N)]
+    fn = sampling.get_sampling_fn(cfg, sde, (2, 5, 16, 16), 1e-5)
+    it = iter(draws)
+    want, _ = fn(model, context=ctx, noise_fn=lambda s: next(it))
+    err = rel_l2(got, want.cpu())
+    print(f"2 ranks x 1 chain with the global-batch hook vs 1 process x 2 chains: rel-L2 = {err:.3e}")
+    assert err < 1e-5
+    # and the per-rank mean (option A) is a different number: the hook really ran
+    fn1 = sampling.get_sampling_fn(cfg, sde, (1, 5, 16, 16), 1e-5)
+    it = iter(draws)
+    alone, _ = fn1(model, context=ctx[:1], noise_fn=lambda s: next(it)[:1])
+    assert rel_l2(alone.cpu(), want[:1].cpu()) > 1e-4
 
 
 def test_registry_behaviour():

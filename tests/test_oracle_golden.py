@@ -108,3 +108,74 @@ def test_vp_sampler_matches_reference():
     out, nfe = O.pc_sampler_vp(P, cfg, (2, 5, 16, 16), torch.from_numpy(g["context"]), noise_fn=lambda shp: next(it))
     assert nfe == int(g["nfe"]) == 80
     assert rel_l2(out, g["sample"]) < TOL
+
+
+# ---- fixtures of tests/golden/make_golden_full.py (BASELINE sizes, `ss`, reference-written checkpoint) ------------
+def test_ss_sampler_matches_reference():
+    from helpers import cfg_ss
+    g = load_golden("tiny_sampler_ss")
+    cfg = cfg_ss()
+    P = synth.synth_state_dict(cfg, int(g["seed"]))
+    it = iter([torch.from_numpy(z) for z in g["noise"]])
+    cond = {"length": torch.from_numpy(g["cond_length"]), "ss": torch.from_numpy(g["cond_ss"])}
+    out, nfe = O.pc_sampler_ve(P, cfg, (2, 8, 16, 16), torch.from_numpy(g["context"]), condition=cond, noise_fn=lambda s: next(it))
+    assert nfe == int(g["nfe"]) and rel_l2(out, g["sample"]) < TOL
+    assert torch.equal(out[:, 4:7], torch.from_numpy(g["cond_ss"]))      # sampling.py:268-270: given and frozen
+
+
+def test_reference_written_checkpoint_layout_and_ema_order():
+    """tests/golden/tiny_checkpoint.pth (written by the reference's save_checkpoint): DataParallel keys, float64 sigmas
+    buffer, EMA shadow list in parameters() order; the oracle on the EMA tensors reproduces the score the reference
+    computed after restore_checkpoint + ema.copy_to, the live tensors the other one."""
+    import os
+    from helpers import GOLDEN, cfg_ckpt
+    from text2protein_amd.arch import param_specs
+    from text2protein_amd.checkpoint import ema_state_dict, strip_module_prefix
+    g = load_golden("tiny_checkpoint_expected")
+    cfg = cfg_ckpt()
+    st = torch.load(os.path.join(GOLDEN, "tiny_checkpoint.pth"), map_location="cpu", weights_only=False)
+    assert sorted(st) == ["ema", "model", "optimizer", "step"] and st["step"] == 1234
+    assert all(k.startswith("module.") for k in st["model"]) and st["model"]["module.sigmas"].dtype == torch.float64
+    specs = param_specs(cfg)
+    assert len(st["ema"]["shadow_params"]) == len(specs)
+    x, labels, ctx = (torch.from_numpy(g[k]) for k in ("x", "labels", "context"))
+    ema = ema_state_dict(cfg, st)
+    want = synth.synth_state_dict(cfg, int(g["ema_seed"]))
+    for s in specs:                                                    # the shadow list is the seed-7 weights, in order
+        assert torch.equal(ema[s.name], want[s.name]), s.name
+    assert rel_l2(O.unet_forward(ema, cfg, x, labels, ctx), g["score"]) < TOL
+    live = {k: v for k, v in strip_module_prefix(st["model"]).items() if k != "sigmas"}
+    assert rel_l2(O.unet_forward(live, cfg, x, labels, ctx), g["score_live"]) < TOL
+
+
+def test_param_tables_match_reference_named_parameters():
+    """arch.param_specs (what the checkpoint loader and the oracle build on) against the reference's
+    named_parameters() for the four shipped YAMLs at the BASELINE sizes."""
+    import json
+    import os
+    from helpers import FULL, GOLDEN
+    from text2protein_amd.arch import param_specs
+    from text2protein_amd.config import load_config
+    root = GOLDEN.rsplit("/tests", 1)[0]
+    tables = json.load(open(os.path.join(GOLDEN, "param_tables.json")))
+    counts = {"test_config": 379.5, "cond_length": 75.0, "cond_length_inpainting": 75.0, "test_config_large": 863.3}
+    for stem, (fname, L, N, _, _, _) in FULL.items():
+        cfg = load_config(os.path.join(root, "configs", fname), **{"data.max_res_num": L, "model.num_scales": N})
+        want = [(n, tuple(s)) for n, s in tables[stem]["named_parameters"]]
+        assert [(s.name, tuple(s.shape)) for s in param_specs(cfg)] == want
+        assert abs(tables[stem]["n_params"] / 1e6 - counts[stem]) < 0.06
+
+
+def test_oracle_at_full_size_cond_length():
+    """One evaluation at a BASELINE size on the CPU (cond_length.yml, L=128, 75 M parameters, a few seconds)."""
+    import os
+    from helpers import FULL, GOLDEN, full_inputs
+    from text2protein_amd.config import load_config
+    root = GOLDEN.rsplit("/tests", 1)[0]
+    fname, L, N, B, T, _ = FULL["cond_length"]
+    cfg = load_config(os.path.join(root, "configs", fname), **{"data.max_res_num": L, "model.num_scales": N})
+    g = load_golden("full_cond_length")
+    x, labels, ctx = full_inputs(cfg, B, T)
+    with torch.no_grad():
+        s = O.unet_forward(synth.synth_state_dict(cfg, 0), cfg, x, labels, ctx)
+    assert rel_l2(s, g["score"]) < TOL

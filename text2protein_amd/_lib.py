@@ -5,7 +5,6 @@ There is no fallback: if the library is missing or a call fails, a ``T2PError`` 
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 from . import build as _build
 
@@ -52,7 +51,10 @@ SIGNATURES = {
     "t2p_engine_score": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "t2p_engine_score_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "t2p_engine_device_bytes": (_i64, [_vp]),
-    "t2p_sampler_create": (_i, [_vp, C.POINTER(SamplerConfig), _vp, C.POINTER(_vp)]),
+    "t2p_sampler_create": (_i, [_vp, C.POINTER(SamplerConfig), _vp, _vp, C.POINTER(_vp)]),
+    "t2p_sampler_set_seed": (_i, [_vp, _u64]),
+    "t2p_sampler_set_norm_allreduce": (_i, [_vp, _vp, _vp, _vp]),
+    "t2p_built_with_ablation": (_i, []),
     "t2p_sampler_destroy": (None, [_vp]),
     "t2p_sampler_set_condition": (_i, [_vp, _vp, _vp]),
     "t2p_sampler_reset": (_i, [_vp, _i, _vp]),
@@ -90,32 +92,42 @@ def lib_path() -> str:
     return _build.LIB
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)   # t2p_allreduce_fn
+
+
 def load(build_if_missing: bool = True):
-    """dlopen libt2p_hip.so (building it first when the sources are newer)."""
+    """dlopen libt2p_hip.so, building it first when it is missing or was built from other sources than the
+    ones in the tree (content hash, text2protein_amd/build.py).  A stale library is never loaded: if the
+    rebuild fails, so does this call."""
     global _lib
     if _lib is not None:
         return _lib
     path = lib_path()
-    if build_if_missing and _build.needs_build():
+    if _build.needs_build():
+        if not build_if_missing:
+            raise T2PError(f"{path} is missing or stale (built from other sources): run `python -m text2protein_amd.build`")
         try:
             _build.build(verbose=False)
         except Exception as e:  # noqa: BLE001
-            if not os.path.exists(path):
-                raise T2PError(f"libt2p_hip.so is missing and could not be built: {e}") from e
-    if not os.path.exists(path):
-        raise T2PError(f"{path} not found: run `python -m text2protein_amd.build` (needs hipcc)")
+            raise T2PError(f"libt2p_hip.so is missing or stale and could not be rebuilt: {e}") from e
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
     _lib = lib
-    # development switches: T2P_DEBUG="key=value,key=value" -> t2p_debug_set (include/t2p.h)
-    for kv in filter(None, os.environ.get("T2P_DEBUG", "").split(",")):
+    return lib
+
+
+def set_plan_switches(spec: str):
+    """Measurement tools only (bench.py --plan, tools/): "key=value,key=value" -> t2p_debug_set (include/t2p.h).
+    The product path never calls this and reads no environment variable."""
+    lib = load()
+    for kv in filter(None, (spec or "").split(",")):
         k, v = kv.split("=")
         if lib.t2p_debug_set(int(k), int(v)) != 0:
-            raise T2PError(f"bad T2P_DEBUG entry {kv}")
-    return lib
+            msg = lib.t2p_last_error()
+            raise T2PError(f"bad plan switch {kv}: {msg.decode() if msg else '?'}")
 
 
 def check(rc: int):

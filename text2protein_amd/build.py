@@ -2,6 +2,7 @@
 so that it travels to the GPU box with the repository snapshot."""
 from __future__ import annotations
 
+import hashlib
 import os
 import re
 import subprocess
@@ -21,11 +22,33 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+STAMP = LIB + ".srchash"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def source_hash(ablation: bool = False) -> str:
+    """sha256 over every source, header and compiler flag: the identity of what libt2p_hip.so was built from.
+    (File times do not survive the copy to the GPU box; contents do.)"""
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS + (["-DT2P_ABLATION"] if ablation else [])).encode())
+    for f in SOURCES + HEADERS:
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def built_hash() -> str:
+    try:
+        with open(STAMP) as f:
+            return f.read().strip()
+    except OSError:
+        return ""
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    """True when the library is missing or was built from other sources than the ones in the tree."""
+    return not os.path.exists(LIB) or built_hash() != source_hash()
 
 
 def scratch_users(remarks: str, kernel_prefix: str = "gemm_dma_kernel"):
@@ -45,14 +68,19 @@ def scratch_users(remarks: str, kernel_prefix: str = "gemm_dma_kernel"):
     return bad
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile every HIP/C++ source for gfx950 and link the shared library; returns its path."""
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> str:
+    """Compile every HIP/C++ source for gfx950 and link the shared library; returns its path.
+
+    ``ablation`` adds -DT2P_ABLATION: the timing-only switches of the LDS-DMA GEMM that skip work (and so give
+    wrong results) exist in such a build only; its stamp never matches, so the next ordinary load rebuilds."""
+    if not force and not ablation and not needs_build():
         return LIB
     hipcc = _hipcc()
     objs = []
     procs = []
-    flags = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+    flags = FLAGS + (["-DT2P_ABLATION"] if ablation else [])
+    if os.path.exists(STAMP):
+        os.remove(STAMP)
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
@@ -87,9 +115,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    with open(STAMP, "w") as f:
+        f.write(("ablation:" if ablation else "") + source_hash(ablation) + "\n")
     return LIB
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, ablation="--ablation" in sys.argv)
     print(LIB)

@@ -226,12 +226,8 @@ __global__ __launch_bounds__(256) void attn_flash_kernel(const FlashArgs a) {
 template <typename TC, int D>
 static int launch_flash_t(const FlashArgs& a, int B, int heads, hipStream_t s) {
   constexpr int smem = 2 * (64 * (D * 2 + 16) + D * (64 * 2 + 8));
-  static bool attr_set = false;
   auto kern = attn_flash_kernel<TC, D>;
-  if (!attr_set) {
-    T2P_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-    attr_set = true;
-  }
+  T2P_TRY(ensure_dynamic_lds((const void*)kern, smem));
   dim3 grid((a.nq + 127) / 128, heads, B);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
   T2P_HIP_CHECK(hipGetLastError());

@@ -100,11 +100,12 @@ int t2p_engine_score_ex(t2p_engine* e, const float* x, const int32_t* labels, co
 
 int64_t t2p_engine_device_bytes(const t2p_engine* e) { return e ? e->impl.device_bytes() : 0; }
 
-int t2p_sampler_create(t2p_engine* e, const t2p_sampler_config* cfg, const float* g_table, t2p_sampler** out) {
+int t2p_sampler_create(t2p_engine* e, const t2p_sampler_config* cfg, const float* g_table, const int32_t* label_table,
+                       t2p_sampler** out) {
   API_BEGIN
   T2P_REQUIRE(e && cfg && out, "null argument");
   t2p_sampler* s = new t2p_sampler(&e->impl, *cfg);
-  int rc = s->impl.init(g_table);
+  int rc = s->impl.init(g_table, label_table);
   if (rc != T2P_OK) {
     delete s;
     return rc;
@@ -121,6 +122,21 @@ int t2p_sampler_set_condition(t2p_sampler* s, const uint8_t* mask, const float* 
   T2P_REQUIRE(s, "null sampler");
   T2P_REQUIRE((mask == nullptr) == (x_initial == nullptr), "mask and x_initial go together");
   return s->impl.set_condition(mask, x_initial);
+  API_END
+}
+
+int t2p_sampler_set_seed(t2p_sampler* s, uint64_t seed) {
+  API_BEGIN
+  T2P_REQUIRE(s, "null sampler");
+  s->impl.set_seed(seed);
+  return T2P_OK;
+  API_END
+}
+
+int t2p_sampler_set_norm_allreduce(t2p_sampler* s, float* device_sums2, t2p_allreduce_fn fn, void* user) {
+  API_BEGIN
+  T2P_REQUIRE(s, "null sampler");
+  return s->impl.set_norm_allreduce(device_sums2, fn, user);
   API_END
 }
 
@@ -371,7 +387,15 @@ int t2p_debug_set(int key, int value) {
   if (key == 14) { g_lowp_residual = value != 0; return T2P_OK; }
   if (key == 15) { set_gemm_thin_conv(value != 0); return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
-  else if (key == 1) set_gemm_debug(value);
+  else if (key == 1) {
+#ifndef T2P_ABLATION
+    if (value & ~(128 | 256)) {
+      set_last_error("ablation bits that skip work exist only in a -DT2P_ABLATION build");
+      return T2P_ERR_INVALID;
+    }
+#endif
+    set_gemm_debug(value);
+  }
   else if (key == 2) set_gemm_geom(value);
   else if (key == 3) set_gemm_splitk(value != 0);
   else if (key == 4) g_raw_copies = value != 0;
@@ -382,6 +406,14 @@ int t2p_debug_set(int key, int value) {
   else if (key == 9) g_lowp_h1 = value != 0;
   else return T2P_ERR_INVALID;
   return T2P_OK;
+}
+
+int t2p_built_with_ablation(void) {
+#ifdef T2P_ABLATION
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 int t2p_profile_begin(void) {

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
+#include <set>
 
 namespace t2p {
 
@@ -21,6 +23,18 @@ bool g_flash_attention = true;
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 const char* get_last_error() { return g_last_error.c_str(); }
+
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;     // (kernel, device)
+  int dev = 0;
+  T2P_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({kernel, dev})) return T2P_OK;
+  T2P_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({kernel, dev});
+  return T2P_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 DevPool::~DevPool() {
@@ -890,7 +904,7 @@ int Engine::set_context(const float* ctx, int B, int T, hipStream_t s) {
 
 // UNetModel.forward (ncsnpp.py:220-263)
 int Engine::score(const float* x, const int* labels, const int* step_counter, float* out, int B, hipStream_t s,
-                  const float* labels_f) {
+                  const float* labels_f, const int* label_table) {
   T2P_REQUIRE(finalized_, "finalize the engine first");
   T2P_REQUIRE(x && out && B > 0 && (labels || step_counter), "score arguments");
   const int L = cfg_.max_res_num, HW = L * L, Cx = cfg_.num_channels, N = cfg_.num_scales;
@@ -900,7 +914,8 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
   POOL_GET(t2, float*, (size_t)R * temb_dim_ * 4);
   POOL_GET(tb, float*, (size_t)R * temb_total_ * 4);
   T2P_REQUIRE(!labels_f || labels, "fractional labels come with integer labels (sigma index)");
-  T2P_TRY(launch_timestep_embedding(labels, labels_f, step_counter, emb, R, nf_, s));
+  T2P_REQUIRE(!label_table || (!labels && step_counter), "a label table goes with the device step counter");
+  T2P_TRY(launch_timestep_embedding(labels, labels_f, step_counter, emb, R, nf_, s, label_table, N));
   T2P_TRY(launch_small_linear(emb, (const float*)pre0_.w, pre0_.b, t1, R, nf_, temb_dim_, 0, s));
   T2P_TRY(launch_small_linear(t1, (const float*)pre1_.w, pre1_.b, t2, R, temb_dim_, temb_dim_, 0, s));
   T2P_TRY(launch_small_linear(t2, (const float*)dense_all_.w, dense_all_.b, tb, R, temb_dim_, temb_total_, 1, s));
@@ -908,7 +923,7 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
   tb_ld_ = labels ? temb_total_ : 0;
   POOL_GET(scale, float*, (size_t)B * 4);
   if (cfg_.scale_by_sigma) {
-    T2P_TRY(launch_gather_label(labels, step_counter, inv_sigma_, scale, B, N, s));
+    T2P_TRY(launch_gather_label(labels, step_counter, inv_sigma_, scale, B, N, s, label_table));
   } else {
     std::vector<float> ones(B, 1.f);
     T2P_HIP_CHECK(hipMemcpyAsync(scale, ones.data(), (size_t)B * 4, hipMemcpyHostToDevice, s));
@@ -982,11 +997,24 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
 // ------------------------------------------------------------------------------------------------
 Sampler::Sampler(Engine* e, const t2p_sampler_config& cfg) : e_(e), cfg_(cfg) {}
 
-int Sampler::init(const float* g_table_host) {
+int Sampler::init(const float* g_table_host, const int32_t* label_table_host) {
   T2P_REQUIRE(cfg_.sde == T2P_SDE_VE, "the fused sampler covers the VE SDE (every shipped config); VP runs through the operator API");
   T2P_REQUIRE(cfg_.N == e_->cfg().num_scales, "sde.N must equal model.num_scales");
   T2P_REQUIRE(cfg_.batch > 0 && cfg_.global_batch >= cfg_.batch && cfg_.n_steps_each >= 1, "sampler config");
+  T2P_REQUIRE(cfg_.eps >= 0.0 && cfg_.eps < 1.0, "eps must lie in [0, T)");
   const int N = cfg_.N;
+  // time label of loop step i: round((T - t_i) (N - 1)) with t = linspace(T, eps, N) (sampling.py:257,
+  // models/utils.py:159-171); equals i only for tiny eps, e.g. 499 of 1000 labels differ at eps = 1e-3
+  std::vector<int32_t> lab(N);
+  if (label_table_host) {
+    std::copy(label_table_host, label_table_host + N, lab.begin());
+  } else {
+    for (int i = 0; i < N; ++i) {
+      const double t = 1.0 + (cfg_.eps - 1.0) * (double)i / (double)(N - 1);
+      lab[i] = (int32_t)std::nearbyint((1.0 - t) * (double)(N - 1));
+    }
+  }
+  for (int i = 0; i < N; ++i) T2P_REQUIRE(lab[i] >= 0 && lab[i] < N, "time label out of range");
   std::vector<float> g(N);
   if (g_table_host) {
     std::copy(g_table_host, g_table_host + N, g.begin());
@@ -1002,6 +1030,7 @@ int Sampler::init(const float* g_table_host) {
   }
   DevPool& pool = e_->pool();
   g_table_ = (float*)pool.persistent((size_t)N * 4);
+  label_table_ = (int*)pool.persistent((size_t)N * 4);
   step_dev_ = (int*)pool.persistent(256);
   const t2p_model_config& m = e_->cfg();
   per_sample_ = (long)m.num_channels * m.max_res_num * m.max_res_num;
@@ -1011,8 +1040,9 @@ int Sampler::init(const float* g_table_host) {
   xmean_ = (float*)pool.persistent((size_t)n_ * 4);
   sq_ws_ = (float*)pool.persistent((size_t)cfg_.batch * 64 * 2 * 4);
   sums_ = (float*)pool.persistent(256);
-  if (!g_table_ || !step_dev_ || !score_ || !noise_ || !xmean_ || !sq_ws_ || !sums_) return T2P_ERR_HIP;
+  if (!g_table_ || !label_table_ || !step_dev_ || !score_ || !noise_ || !xmean_ || !sq_ws_ || !sums_) return T2P_ERR_HIP;
   T2P_HIP_CHECK(hipMemcpy(g_table_, g.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+  T2P_HIP_CHECK(hipMemcpy(label_table_, lab.data(), (size_t)N * 4, hipMemcpyHostToDevice));
   T2P_HIP_CHECK(hipMemset(step_dev_, 0, 256));
   return T2P_OK;
 }
@@ -1021,6 +1051,13 @@ int Sampler::reset(int step, hipStream_t s) {
   T2P_REQUIRE(step >= 0 && step < cfg_.N, "step out of range");
   T2P_HIP_CHECK(hipMemcpyAsync(step_dev_, &step, sizeof(int), hipMemcpyHostToDevice, s));
   T2P_HIP_CHECK(hipStreamSynchronize(s));
+  host_step_ = step;
+  return T2P_OK;
+}
+
+int Sampler::set_norm_allreduce(float* sums, t2p_allreduce_fn fn, void* user) {
+  T2P_REQUIRE((sums == nullptr) == (fn == nullptr), "the sums buffer and the all-reduce callback go together");
+  sums_ext_ = sums; allreduce_ = fn; allreduce_user_ = user;
   return T2P_OK;
 }
 
@@ -1028,22 +1065,30 @@ int Sampler::reset(int step, hipStream_t s) {
 int Sampler::step(float* x, float* x_mean, const float* nc, const float* np, hipStream_t s) {
   T2P_REQUIRE(x, "x is null");
   T2P_REQUIRE(cfg_.n_steps_each == 1 || !nc, "injected corrector noise supports n_steps_each == 1");
+  // the schedule tables hold N entries: a step past the end of the run is a caller error (t2p_sampler_reset rewinds)
+  T2P_REQUIRE(host_step_ >= 0 && host_step_ < cfg_.N, "PC step index beyond sde.N: call t2p_sampler_reset before another run");
+  // Langevin batch mean over global_batch chains (reference DataParallel run): needs the norm sums of the other
+  // processes, i.e. the all-reduce hook; without it the mean runs over this process's chains
+  T2P_REQUIRE(cfg_.global_batch == cfg_.batch || allreduce_, "global_batch > batch needs t2p_sampler_set_norm_allreduce");
   const int B = cfg_.batch;
+  float* sums = allreduce_ ? sums_ext_ : sums_;
   for (int k = 0; k < cfg_.n_steps_each; ++k) {
-    T2P_TRY(e_->score(x, nullptr, step_dev_, score_, B, s));
+    T2P_TRY(e_->score(x, nullptr, step_dev_, score_, B, s, nullptr, label_table_));
     const float* z = nc;
     if (!z) {
       T2P_TRY(launch_philox_normal(noise_, n_, cfg_.seed, 2ull * k + 2, step_dev_, s));
       z = noise_;
     }
-    T2P_TRY(launch_langevin_norms(score_, z, B, per_sample_, sq_ws_, sums_, s));
+    T2P_TRY(launch_langevin_norms(score_, z, B, per_sample_, sq_ws_, sums, s));
+    if (allreduce_) {     // sum_b ||grad_b||, sum_b ||noise_b|| over every process's chains (SURVEY 8(e) option B)
+      const int rc = allreduce_(sums, (void*)s, allreduce_user_);
+      if (rc != 0) { set_last_error("the norm all-reduce callback failed with status " + std::to_string(rc)); return T2P_ERR_STATE; }
+    }
     SdeUpdateArgs a;
     a.x = x; a.score = score_; a.noise = z; a.mask = mask_; a.x_initial = x_init_; a.x_out = x; a.n = n_;
-    // batch-mean norms over this process's chains; callers wanting global-batch semantics
-    // all-reduce sums_ themselves through the operator API (SURVEY 8(e) option B)
-    T2P_TRY(launch_langevin_update(a, sums_, (float)B, (float)cfg_.snr, 1.f, s));
+    T2P_TRY(launch_langevin_update(a, sums, (float)(allreduce_ ? cfg_.global_batch : B), (float)cfg_.snr, 1.f, s));
   }
-  T2P_TRY(e_->score(x, nullptr, step_dev_, score_, B, s));
+  T2P_TRY(e_->score(x, nullptr, step_dev_, score_, B, s, nullptr, label_table_));
   const float* z = np;
   if (!z) {
     T2P_TRY(launch_philox_normal(noise_, n_, cfg_.seed, 1, step_dev_, s));
@@ -1052,8 +1097,9 @@ int Sampler::step(float* x, float* x_mean, const float* nc, const float* np, hip
   SdeUpdateArgs a;
   a.x = x; a.score = score_; a.noise = z; a.mask = mask_; a.x_initial = x_init_; a.x_out = x;
   a.x_mean_out = x_mean ? x_mean : xmean_; a.n = n_;
-  T2P_TRY(launch_predictor_update(a, g_table_, step_dev_, 0.f, cfg_.probability_flow, s));
+  T2P_TRY(launch_predictor_update(a, g_table_, step_dev_, 0.f, cfg_.probability_flow, s, cfg_.N));
   T2P_TRY(launch_add_int(step_dev_, 1, s));
+  ++host_step_;
   return T2P_OK;
 }
 
@@ -1063,11 +1109,13 @@ Sampler::~Sampler() {
 
 int Sampler::step_graph(float* x, float* x_mean, hipStream_t s) {
   T2P_REQUIRE(x && x_mean, "step_graph needs explicit x and x_mean buffers");
+  T2P_REQUIRE(!allreduce_, "the captured step does not run the norm all-reduce hook: use t2p_sampler_step");
+  T2P_REQUIRE(host_step_ >= 0 && host_step_ < cfg_.N, "PC step index beyond sde.N: call t2p_sampler_reset before another run");
   if (eager_steps_ < 1) {            // one eager step first: fills the activation pool (no hipMalloc under capture)
     ++eager_steps_;
     return step(x, x_mean, nullptr, nullptr, s);
   }
-  if (graph_exec_ && (graph_x_ != x || graph_xm_ != x_mean || graph_mask_ != mask_)) {
+  if (graph_exec_ && (graph_x_ != x || graph_xm_ != x_mean || graph_mask_ != mask_ || graph_seed_ != cfg_.seed)) {
     (void)hipGraphExecDestroy(graph_exec_);
     graph_exec_ = nullptr;
   }
@@ -1075,14 +1123,16 @@ int Sampler::step_graph(float* x, float* x_mean, hipStream_t s) {
     hipGraph_t graph = nullptr;
     T2P_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = step(x, x_mean, nullptr, nullptr, s);
+    --host_step_;                        // the capture enqueued nothing: the replay below is the step
     const hipError_t ec = hipStreamEndCapture(s, &graph);
     if (rc != T2P_OK) return rc;
     T2P_HIP_CHECK(ec);
     T2P_HIP_CHECK(hipGraphInstantiate(&graph_exec_, graph, nullptr, nullptr, 0));
     (void)hipGraphDestroy(graph);
-    graph_x_ = x; graph_xm_ = x_mean; graph_mask_ = mask_;
+    graph_x_ = x; graph_xm_ = x_mean; graph_mask_ = mask_; graph_seed_ = cfg_.seed;
   }
   T2P_HIP_CHECK(hipGraphLaunch(graph_exec_, s));
+  ++host_step_;
   return T2P_OK;
 }
 

@@ -88,8 +88,9 @@ class Engine {
   int finalize();
   int set_context(const float* ctx, int B, int T, hipStream_t s);
   // labels == nullptr: every row uses *step_counter (device int)
+  // label_table (with step_counter): device int[num_scales], the time label of loop step i (fused sampler)
   int score(const float* x, const int* labels, const int* step_counter, float* out, int B, hipStream_t s,
-            const float* labels_f = nullptr);
+            const float* labels_f = nullptr, const int* label_table = nullptr);
   int64_t device_bytes() const { return (int64_t)pool_.held_bytes(); }
   const t2p_model_config& cfg() const { return cfg_; }
   DevPool& pool() { return pool_; }
@@ -148,8 +149,13 @@ class Engine {
 class Sampler {
  public:
   Sampler(Engine* e, const t2p_sampler_config& cfg);
-  int init(const float* g_table_host);
+  int init(const float* g_table_host, const int32_t* label_table_host);
   int set_condition(const uint8_t* mask, const float* x_initial) { mask_ = mask; x_init_ = x_initial; return T2P_OK; }
+  void set_seed(uint64_t seed) { cfg_.seed = seed; }
+  // global-batch Langevin step size (reference under DataParallel, sampling.py:193-195): `sums` is a caller-owned
+  // device float[2] the norm sums of this process's chains are written to; `fn` must sum it over all processes
+  // in stream order before returning control (e.g. one RCCL all_reduce enqueued on `stream`)
+  int set_norm_allreduce(float* sums, t2p_allreduce_fn fn, void* user);
   int reset(int step, hipStream_t s);
   int step(float* x, float* x_mean, const float* nc, const float* np, hipStream_t s);
   // step() through a captured hipGraph (device noise only): first call with a given (x, x_mean,
@@ -170,6 +176,12 @@ class Sampler {
   float* sq_ws_ = nullptr;
   float* sums_ = nullptr;
   float* xmean_ = nullptr;
+  int* label_table_ = nullptr;     // device int[N]: time label of loop step i
+  int host_step_ = 0;              // host mirror of *step_dev_ (bounds check: the tables have N entries)
+  float* sums_ext_ = nullptr;
+  t2p_allreduce_fn allreduce_ = nullptr;
+  void* allreduce_user_ = nullptr;
+  uint64_t graph_seed_ = 0;
   long n_ = 0, per_sample_ = 0;
   hipGraphExec_t graph_exec_ = nullptr;
   float* graph_x_ = nullptr;

@@ -706,13 +706,14 @@ int launch_nchw_to_nhwc(const float* x, float* out, int B, int C, int HW, int Cp
 }
 
 // ================================== time embedding ========================================================
-__global__ void timestep_embedding_kernel(const int* labels, const float* labels_f, const int* step_counter, float* emb,
-                                          int rows, int dim) {
+__global__ void timestep_embedding_kernel(const int* labels, const float* labels_f, const int* step_counter,
+                                          const int* label_table, int n_table, float* emb, int rows, int dim) {
   const int half = dim / 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * dim) return;
   const int r = i / dim, k = i - r * dim;
-  const float t = labels_f ? labels_f[r] : (float)(labels ? labels[r] : *step_counter);
+  // fused sampler: the time label of loop step i is label_table[i] (get_score_fn, models/utils.py:159-171)
+  const float t = labels_f ? labels_f[r] : (float)(labels ? labels[r] : (label_table ? label_table[min(max(*step_counter, 0), n_table - 1)] : *step_counter));
   // reference: emb = log(10000) / (half - 1) as a python float, then exp(arange * -emb) in fp32
   const float e = (float)(9.210340371976184 / (double)(half - 1));
   float val = 0.f;
@@ -726,11 +727,12 @@ __global__ void timestep_embedding_kernel(const int* labels, const float* labels
 }
 
 int launch_timestep_embedding(const int* labels, const float* labels_f, const int* step_counter, float* emb, int rows, int dim,
-                              hipStream_t s) {
+                              hipStream_t s, const int* label_table, int n_table) {
   T2P_REQUIRE((labels || labels_f || step_counter) && emb && dim >= 4, "timestep embedding arguments");
+  T2P_REQUIRE(!label_table || (step_counter && n_table > 0), "label_table needs the step counter and its length");
   const int tot = rows * dim;
-  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, labels, labels_f, step_counter, emb, rows,
-                     dim);
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, labels, labels_f, step_counter, label_table, n_table,
+                     emb, rows, dim);
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }
@@ -839,8 +841,10 @@ int launch_langevin_update(const SdeUpdateArgs& a, const float* sums, float batc
 }
 
 __global__ __launch_bounds__(256) void predictor_update_kernel(SdeUpdateArgs a, const float* G_table, const int* step_counter,
-                                                               float G_value, int probability_flow) {
-  const float G = G_table ? G_table[*step_counter] : G_value;
+                                                               float G_value, int probability_flow, int n_table) {
+  // the host refuses steps >= N (Sampler::step); the clamp is a second guard against reading past the table
+  const int si = G_table ? min(max(*step_counter, 0), n_table - 1) : 0;
+  const float G = G_table ? G_table[si] : G_value;
   const float g2 = G * G * (probability_flow ? 0.5f : 1.f);
   const float gz = probability_flow ? 0.f : G;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) {
@@ -854,12 +858,12 @@ __global__ __launch_bounds__(256) void predictor_update_kernel(SdeUpdateArgs a, 
 }
 
 int launch_predictor_update(const SdeUpdateArgs& a, const float* G_table, const int* step_counter, float G_value,
-                            int probability_flow, hipStream_t s) {
+                            int probability_flow, hipStream_t s, int n_table) {
   T2P_REQUIRE(a.x && a.score && a.noise && a.x_out && a.n > 0, "predictor_update arguments");
   T2P_REQUIRE(!a.mask || a.x_initial, "mask needs x_initial");
-  T2P_REQUIRE(!G_table || step_counter, "G_table needs the step counter");
+  T2P_REQUIRE(!G_table || (step_counter && n_table > 0), "G_table needs the step counter and its length");
   hipLaunchKernelGGL(predictor_update_kernel, dim3(ew_grid(a.n)), dim3(256), 0, s, a, G_table, step_counter, G_value,
-                     probability_flow);
+                     probability_flow, n_table);
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }
@@ -950,16 +954,18 @@ int launch_convert(const float* in, void* out, int dtype, long n, hipStream_t s)
 }
 
 // out[b] = table[label_b]  (1 / sigma of the sample's time label; ncsnpp.py:223,259-261)
-__global__ void gather_label_kernel(const int* labels, const int* step_counter, const float* table, float* out, int B, int N) {
+__global__ void gather_label_kernel(const int* labels, const int* step_counter, const int* label_table, const float* table, float* out,
+                                    int B, int N) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  int l = labels ? labels[b] : *step_counter;
+  int l = labels ? labels[b] : (label_table ? label_table[min(max(*step_counter, 0), N - 1)] : *step_counter);
   l = l < 0 ? 0 : (l >= N ? N - 1 : l);
   out[b] = table[l];
 }
-int launch_gather_label(const int* labels, const int* step_counter, const float* table, float* out, int B, int N, hipStream_t s) {
+int launch_gather_label(const int* labels, const int* step_counter, const float* table, float* out, int B, int N, hipStream_t s,
+                        const int* label_table) {
   T2P_REQUIRE((labels || step_counter) && table && out && B > 0, "gather_label arguments");
-  hipLaunchKernelGGL(gather_label_kernel, dim3((B + 63) / 64), dim3(64), 0, s, labels, step_counter, table, out, B, N);
+  hipLaunchKernelGGL(gather_label_kernel, dim3((B + 63) / 64), dim3(64), 0, s, labels, step_counter, label_table, table, out, B, N);
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }

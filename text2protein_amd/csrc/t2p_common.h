@@ -80,6 +80,10 @@ const char* get_last_error();
     if (_rc != T2P_OK) return _rc;                                                            \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel,
+// current device), whichever device the calling thread has selected (engine.cpp)
+int ensure_dynamic_lds(const void* kernel, int bytes);
+
 // ---- GEMM / implicit-GEMM convolution ------------------------------------------------------------
 // C[z][m][n] = alpha * ( sum_k A[z][m][k] * Bw[z][n][k] + bias_n[n] + bias_m[m]
 //                        + bias_bn[m / rows_per_batch][n] + R[z][res_row(m)][n] )

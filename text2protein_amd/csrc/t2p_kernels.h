@@ -70,8 +70,9 @@ int launch_nchw_to_nhwc(const float* x, float* out, int B, int C, int HW, int Cp
 // captured graph of one PC step can be replayed.
 // labels_f (optional): fractional time values for the embedding (VP path: labels = t * (N - 1),
 // reference models/utils.py:150-152); the sigma lookup always uses the integer labels
+// label_table (optional, with step_counter): the label is label_table[*step_counter] instead of *step_counter
 int launch_timestep_embedding(const int* labels, const float* labels_f, const int* step_counter, float* emb, int rows,
-                              int dim, hipStream_t s);
+                              int dim, hipStream_t s, const int* label_table = nullptr, int n_table = 0);
 // out[r][n] = bias[n] + sum_k act(in[r][k]) * W[n][k]   (fp32; act = SiLU when silu != 0)
 int launch_small_linear(const float* in, const float* W, const float* bias, float* out, int rows, int K, int N,
                         int silu, hipStream_t s);
@@ -97,7 +98,7 @@ int launch_langevin_update(const SdeUpdateArgs& a, const float* sums, float batc
 // predictor: x_mean = x + G^2 * score * (0.5 if probability_flow); x = x_mean + (0 if pf else G) z
 // G = G_table[*step_counter] when G_table != null, else G_value
 int launch_predictor_update(const SdeUpdateArgs& a, const float* G_table, const int* step_counter, float G_value,
-                            int probability_flow, hipStream_t s);
+                            int probability_flow, hipStream_t s, int n_table = 0);
 // noise[i] = N(0,1) from Philox4x32-10 keyed by (seed, stream); counter = element index / 4
 int launch_philox_normal(float* out, long n, unsigned long long seed, unsigned long long stream,
                          const int* step_counter, hipStream_t s);
@@ -111,7 +112,7 @@ int launch_attention_flash(int dtype, const void* q, long ldq, const void* k, lo
 
 int launch_convert(const float* in, void* out, int dtype, long n, hipStream_t s);
 int launch_gather_label(const int* labels, const int* step_counter, const float* table, float* out, int B, int N,
-                        hipStream_t s);
+                        hipStream_t s, const int* label_table = nullptr);
 int launch_apply_mask(float* x, const unsigned char* mask, const float* x_initial, long n, hipStream_t s);
 int launch_decode6d(const float* x, int B, int C, int L, float* clipped, float* absval, int* lengths, hipStream_t s);
 int launch_embedding_gather(const void* table, int dtype, const int* ids, float* out, long ntok, int dim, int vocab, int* bad, hipStream_t s);

@@ -10,6 +10,9 @@ GPU with ``--batch_size B/G``) and the only data-path collective of a run is the
 from __future__ import annotations
 
 import os
+import socket
+import subprocess
+import sys
 
 import torch
 
@@ -27,10 +30,65 @@ def init_process_group(device=None, backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     if backend is None:
-        backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
+        # T2P_DIST_BACKEND=gloo: rehearsals with several ranks on one card (RCCL wants one GPU per rank)
+        backend = os.environ.get("T2P_DIST_BACKEND") or (
+            "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo")
     kw = {"device_id": torch.device(device)} if backend == "nccl" else {}
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return dist
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_local(n_ranks: int, argv, env_extra=None, timeout=None) -> int:
+    """Start ``n_ranks`` fresh child interpreters running ``argv`` (a script path + its arguments), one rank per
+    GPU of this node, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way
+    ``torch.distributed.run`` sets them; returns the largest exit code.
+
+    This is what ``python bench.py --gpus N`` does when it is started directly (no WORLD_SIZE in the
+    environment).  It must run BEFORE the calling process touches the GPU: the children are new processes (never
+    a re-exec of a process that holds a GPU context), and the parent only waits for them."""
+    port = free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable, *argv], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait(timeout=timeout)))
+    except BaseException:
+        for p in procs:                    # one rank failed or we were interrupted: do not leave the others behind
+            if p.poll() is None:
+                p.kill()
+        raise
+    return rc
+
+
+def barrier(dist=None, device=None):
+    """Process-group barrier followed by a device synchronisation: both sides of a timed region."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value: float, dist=None, device="cpu") -> float:
+    """The slowest rank's figure (a timed region ends when the last rank is done)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def chain_ids(chains_per_rank: int, rank: int):

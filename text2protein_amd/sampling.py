@@ -161,6 +161,22 @@ class _NoiseSource:
 
 _default_noise = _NoiseSource()
 
+_M64 = (1 << 64) - 1
+
+
+def call_seed(seed: int, call: int) -> int:
+    """Seed of the ``call``-th invocation of a sampler built with ``seed``.  The reference draws fresh
+    ``torch.randn`` noise on every call of ``pc_sampler`` (sampling.py:253,164,192); the counter-based
+    generator here is keyed by (seed, stream, step) alone, so the call index is folded into the seed
+    (call 0 keeps ``seed`` itself; later calls go through one splitmix64 round)."""
+    seed, call = int(seed) & _M64, int(call)
+    if call == 0:
+        return seed
+    z = (seed + 0x9E3779B97F4A7C15 * call) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
 
 @register_predictor(name="reverse_diffusion")
 class ReverseDiffusionPredictor(Predictor):
@@ -242,7 +258,12 @@ class PCStepper:
     """Handle on the fused C++ sampler (t2p_sampler_*): one ``step`` = one iteration of the loop
     body of the reference ``pc_sampler`` (sampling.py:279-285) enqueued on the current stream."""
 
-    def __init__(self, model, sde, batch, snr, n_steps=1, probability_flow=False, denoise=True, eps=1e-5, seed=0):
+    def __init__(self, model, sde, batch, snr, n_steps=1, probability_flow=False, denoise=True, eps=1e-5, seed=0,
+                 global_batch=None, all_reduce=None):
+        """``global_batch`` / ``all_reduce``: the Langevin batch means run over ``global_batch`` chains spread
+        over several processes (the reference's DataParallel semantics, sampling.py:193-195): ``all_reduce`` is
+        called once per corrector step with a 2-float device tensor it must sum over the processes in place,
+        in stream order (``text2protein_amd.distributed.allreduce_norm_sums``)."""
         if not isinstance(sde, sde_lib.VESDE):
             raise T2PError("the fused stepper covers the VE SDE; other SDEs run through the predictor/corrector classes")
         if not isinstance(model, HipScoreModel):
@@ -258,13 +279,36 @@ class PCStepper:
         sc.probability_flow = int(bool(probability_flow))
         sc.denoise = int(bool(denoise))
         sc.eps = float(eps)
-        sc.batch = sc.global_batch = int(batch)
-        sc.seed = int(seed)
+        sc.batch = int(batch)
+        sc.global_batch = int(global_batch or batch)
+        if (all_reduce is None) != (sc.global_batch == sc.batch):
+            raise T2PError("global_batch > batch and the all_reduce callable go together")
+        sc.seed = int(seed) & _M64
         g = sde.g_table(eps)                       # the reference's own float32 arithmetic
+        labels = sde.label_table(eps)
         h = C.c_void_p()
-        check(self.lib.t2p_sampler_create(model._h, C.byref(sc), C.c_void_p(g.data_ptr()), C.byref(h)))
+        check(self.lib.t2p_sampler_create(model._h, C.byref(sc), C.c_void_p(g.data_ptr()), C.c_void_p(labels.data_ptr()),
+                                          C.byref(h)))
         self._h = h
         self._keep = ()
+        self.N = int(sde.N)
+        if all_reduce is not None:
+            self._sums = torch.zeros(2, device=model.device, dtype=torch.float32)
+
+            def _cb(_ptr, _stream, _user, _t=self._sums, _fn=all_reduce):
+                try:
+                    _fn(_t)                        # sums the caller-owned buffer the sampler just filled
+                    return 0
+                except Exception as e:  # noqa: BLE001  (must not unwind through the C frame)
+                    self._cb_error = e
+                    return 1
+
+            self._cb = _lib.ALLREDUCE_FN(_cb)       # keep the trampoline alive as long as the sampler
+            self._cb_error = None
+            check(self.lib.t2p_sampler_set_norm_allreduce(self._h, ptr(self._sums), self._cb, None))
+
+    def set_seed(self, seed):
+        check(self.lib.t2p_sampler_set_seed(self._h, int(seed) & _M64))
 
     def set_condition(self, mask_u8=None, x_initial=None):
         self._keep = (mask_u8, x_initial)          # the C side borrows these pointers
@@ -321,41 +365,51 @@ def apply_conditions(x, condition):
 
 
 def get_pc_sampler(sde, shape, predictor, corrector, snr, n_steps=1, probability_flow=False, denoise=True,
-                   eps=1e-3, device="cuda", seed=0, force_classes=False):
+                   eps=1e-3, device="cuda", seed=0, force_classes=False, global_batch=None, all_reduce=None):
     """Create a Predictor-Corrector (PC) sampler (sampling.py:213-291).
 
     Extra keyword arguments (not in the reference): ``seed`` of the on-device noise generator;
-    ``force_classes`` runs the predictor / corrector objects even where the fused route applies.
-    The returned ``pc_sampler(model, condition=None, context=None, noise_fn=None, n_iter=None)``
+    ``force_classes`` runs the predictor / corrector objects even where the fused route applies;
+    ``global_batch`` + ``all_reduce`` give the Langevin step size the reference computes when its batch is
+    spread over devices (mean norms over all ``global_batch`` chains, SURVEY.md 8(e) option B).
+    The returned ``pc_sampler(model, condition=None, context=None, noise_fn=None, n_iter=None, call_index=None)``
     accepts ``noise_fn(shape) -> CPU tensor`` to inject the standard-normal draws in the
     reference's order (prior, then corrector and predictor of each step), and ``n_iter`` to stop
-    after that many PC steps (benchmarks / tests).
+    after that many PC steps (benchmarks / tests).  Like the reference, every call draws fresh noise:
+    call number k of this sampler uses ``call_seed(seed, k)``; ``call_index`` pins k (reproducing a call).
     """
     device = torch.device("cuda:0" if str(device) == "cuda" else device)
     if device.type != "cuda":
         raise T2PError("the HIP sampler needs a GPU device (no CPU fallback)")
     fused_ok = (isinstance(sde, sde_lib.VESDE) and predictor is ReverseDiffusionPredictor
                 and corrector is LangevinCorrector and not force_classes)
-    state = {"sampler": None, "model": None}
+    state = {"sampler": None, "model": None, "calls": 0}
 
     def _fused_sampler(model):
         if state["sampler"] is None or state["model"] is not model:
-            state["sampler"] = PCStepper(model, sde, shape[0], snr, n_steps, probability_flow, denoise, eps, seed)
+            state["sampler"] = PCStepper(model, sde, shape[0], snr, n_steps, probability_flow, denoise, eps, seed,
+                                         global_batch=global_batch, all_reduce=all_reduce)
             state["model"] = model
         return state["sampler"]
 
-    def pc_sampler(model, condition=None, context=None, noise_fn=None, n_iter=None):
+    def pc_sampler(model, condition=None, context=None, noise_fn=None, n_iter=None, call_index=None):
         """The PC sampler function -> (samples, number of function evaluations)."""
         lib = _lib.load()
         torch.cuda.set_device(device)
         n_iter = sde.N if n_iter is None else int(n_iter)
-        noise = _NoiseSource(seed, noise_fn)
+        if n_iter > sde.N:
+            raise ValueError(f"n_iter {n_iter} exceeds sde.N {sde.N}")
+        if call_index is None:
+            call_index = state["calls"]
+            state["calls"] += 1
+        run_seed = call_seed(seed, call_index)
+        noise = _NoiseSource(run_seed, noise_fn)
         with torch.no_grad():
             # Initial sample (sde_lib.py:229-230): the reference draws on the CPU and moves it
             if noise_fn is not None:
                 x = (noise_fn(tuple(shape)) * sde.prior_scale()).to(device, torch.float32)
             else:
-                x = _device_randn_like(torch.empty(*shape, device=device), int(seed), 0) * sde.prior_scale()
+                x = _device_randn_like(torch.empty(*shape, device=device), run_seed, 0) * sde.prior_scale()
             x, conditional_mask = apply_conditions(x, condition)
             x = x.float().contiguous()
             x_initial = x.detach().clone()
@@ -370,6 +424,7 @@ def get_pc_sampler(sde, shape, predictor, corrector, snr, n_steps=1, probability
             if fused_ok and isinstance(model, HipScoreModel):
                 stepper = _fused_sampler(model)
                 stepper.set_condition(mask_u8, x_initial if conditioned else None)
+                stepper.set_seed(run_seed)
                 stepper.reset(0)
                 x_mean = torch.empty_like(x)
                 for _ in range(n_iter):
@@ -379,6 +434,8 @@ def get_pc_sampler(sde, shape, predictor, corrector, snr, n_steps=1, probability
                     stepper.step(x, x_mean, nc, npred)
             else:
                 ReverseDiffusionPredictor.noise = LangevinCorrector.noise = noise
+                LangevinCorrector.all_reduce = staticmethod(all_reduce) if all_reduce is not None else None
+                LangevinCorrector.global_batch = global_batch
                 timesteps = torch.linspace(sde.T, eps, sde.N, device=device)
                 predictor_update_fn = functools.partial(shared_predictor_update_fn, sde=sde, predictor=predictor,
                                                         probability_flow=probability_flow)

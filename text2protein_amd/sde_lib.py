@@ -69,6 +69,13 @@ class VESDE(SDE):
         ts = torch.linspace(self.T, eps, self.N)
         return self.discretize_coeffs(ts)[1].float().contiguous()
 
+    def label_table(self, eps):
+        """Time label the score network receives at loop step i: ``round((T - t_i) (N - 1))`` in the
+        reference's float32 arithmetic (models/utils.py:159-171 on ``linspace(T, eps, N)``).  It equals
+        ``i`` only for tiny eps: with get_pc_sampler's own default eps = 1e-3 and N = 1000, 499 labels differ."""
+        ts = torch.linspace(self.T, eps, self.N)
+        return torch.round((self.T - ts) * (self.N - 1)).long().to(torch.int32).contiguous()
+
 
 class VPSDE(SDE):
     def __init__(self, beta_min=0.1, beta_max=20, N=1000):
