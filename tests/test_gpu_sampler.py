@@ -116,9 +116,9 @@ def test_ss_condition_matches_reference_run():
 
 
 def test_fused_route_uses_the_reference_time_labels_at_large_eps():
-    """get_pc_sampler's own default eps = 1e-3: the label round((T - t_i)(N - 1)) differs from the loop index for
-    about half of the steps (N = 1000: 499 of them; here N = 200).  Fused and class routes must agree, and the
-    label table is the reference's."""
+    """The label round((T - t_i)(N - 1)) equals the loop index only for tiny eps: with get_pc_sampler's own default
+    eps = 1e-3 and N = 1000, 499 labels differ and the last one is 998.  Run here with eps = 1e-2, N = 200 (149 labels
+    differ): the fused route must agree with the class route, which computes the label as the reference does."""
     from text2protein_amd import synth, sde_lib, sampling
     from text2protein_amd.config import tiny_config
     from text2protein_amd.model import HipScoreModel
@@ -126,12 +126,15 @@ def test_fused_route_uses_the_reference_time_labels_at_large_eps():
     cfg = tiny_config(**{"model.num_scales": N})
     cfg.device = "cuda"
     sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=N)
-    lab = sde.label_table(1e-3)
-    assert int((lab != torch.arange(N)).sum()) > N // 4 and int(lab[-1]) == N - 2      # eps = 1e-3: the last label is N - 2
+    eps = 1e-2
+    lab = sde.label_table(eps)
+    assert int((lab != torch.arange(N)).sum()) > N // 2 and int(lab[-1]) == N - 3
     assert torch.equal(sde.label_table(1e-5), torch.arange(N, dtype=torch.int32))     # the CLI's eps: label == index
     t = load_golden("tables")
     sde1k = sde_lib.VESDE(sigma_min=0.01, sigma_max=100.0, N=1000)
     assert torch.equal(sde1k.label_table(1e-5).long(), torch.from_numpy(t["labels_1000"]))
+    lab1k = sde1k.label_table(1e-3)
+    assert int((lab1k != torch.arange(1000)).sum()) == 499 and int(lab1k[-1]) == 998
     model = HipScoreModel(cfg, dtype="f32")
     model.load_state_dict(synth.synth_state_dict(cfg, 0))
     ctx = synth.synth_context(2, 3, cfg.model.context_dim, 0)
@@ -139,12 +142,12 @@ def test_fused_route_uses_the_reference_time_labels_at_large_eps():
     draws = [torch.randn(2, 5, 16, 16, generator=g) for _ in range(1 + 2 * N)]
     outs = []
     for force in (False, True):
-        fn = sampling.get_sampling_fn(cfg, sde, (2, 5, 16, 16), 1e-3, force_classes=force)
+        fn = sampling.get_sampling_fn(cfg, sde, (2, 5, 16, 16), eps, force_classes=force)
         it = iter(draws)
         out, _ = fn(model, context=ctx, noise_fn=lambda s: next(it))
         outs.append(out.cpu())
     err = rel_l2(outs[0], outs[1])
-    print(f"eps = 1e-3, N = {N}: fused vs classes rel-L2 = {err:.3e}")
+    print(f"eps = {eps}, N = {N}: fused vs classes rel-L2 = {err:.3e}")
     assert err < 1e-5
 
 
