@@ -286,10 +286,49 @@ def test_dma_kernel_variants_agree(lib, geom, ring):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("geom", [3, 4])
+def test_conv_halo_kernel(lib, geom):
+    """3x3 convolution with the input halo resident in LDS (conv_halo_kernel; forced 256 x 256 / 512 x 128 tiles so that
+    small maps select it): maps of 16 .. 128 pixels per row incl. a width that is not a power of two, tiles that are a
+    whole sample / several image rows / a fraction of an image row pair, first and last tiles of a sample (zero rows
+    above and below), Cout not a multiple of the tile; exact products, so only the fp32 summation order differs from
+    the reference, and the implicit-GEMM kernel (halo switched off) must agree to the same level."""
+    try:
+        check(lib, lib.t2p_debug_set(2, geom))
+        g = torch.Generator().manual_seed(geom)
+        shapes = [(3, 16, 16, 64, 256), (2, 16, 32, 128, 128), (1, 32, 48, 64, 192), (2, 8, 64, 192, 256), (1, 8, 128, 64, 320),
+                  (2, 64, 64, 64, 128)]
+        for dt in (1, 2):
+            td = TDT[dt]
+            for (B, H, W, Cin, Cout) in shapes:
+                x = torch.randn(B, Cin, H, W, generator=g).to(td)
+                w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(td)
+                b = torch.randn(Cout, generator=g)
+                ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+                outs = []
+                for halo in (1, 0):
+                    check(lib, lib.t2p_debug_set(16, halo))
+                    out = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+                    check(lib, lib.t2p_op_conv3x3(dt, P(dev(x.permute(0, 2, 3, 1))), 0, P(dev(w.permute(0, 2, 3, 1))), P(dev(b)), P(out),
+                                                  B, H, W, Cin, Cout, 0, None))
+                    torch.cuda.synchronize()
+                    outs.append(out.cpu())
+                e = rel_l2(outs[0], ref)
+                assert e < 3e-6, (geom, dt, B, H, W, Cin, Cout, e)
+                assert rel_l2(outs[0], outs[1]) < 3e-6
+                if (H * W) % (256 if geom == 3 else 512) == 0:
+                    assert not torch.equal(outs[0], outs[1]), "the halo kernel did not run"     # another summation order
+    finally:
+        lib.t2p_debug_set(2, 0)
+        lib.t2p_debug_set(16, 1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("geom,ring", [(3, 2), (3, 1), (1, 0), (6, 2)])
 def test_dma_issue_order_does_not_change_results(lib, geom, ring):
     """The staggered DMA issue order of the two wave halves (default) against the same kernel with the
-    stagger switched off (debug bits 128 / 256): only the instruction order differs, so bit-identical."""
+    stagger switched off (debug bits 128 / 256), and the register epilogue of the 16x16x32 kernels against the
+    LDS-staged one (bit 4096): only the instruction order / the way the values reach memory differs, so bit-identical."""
     try:
         check(lib, lib.t2p_debug_set(2, geom))
         check(lib, lib.t2p_debug_set(8, ring))
@@ -299,14 +338,30 @@ def test_dma_issue_order_does_not_change_results(lib, geom, ring):
         w = dev((torch.randn(Cout, 9 * Cin, generator=g) / (9 * Cin) ** 0.5).half())
         b = dev(torch.randn(Cout, generator=g))
         outs = []
-        for mask in (0, 128, 256):
+        for mask in (0, 128, 256, 4096):
             check(lib, lib.t2p_debug_set(1, mask))
             out = torch.full((B, H, W, Cout), float("nan"), device="cuda")
             check(lib, lib.t2p_op_conv3x3(2, P(x), 0, P(w), P(b), P(out), B, H, W, Cin, Cout, 0, None))
             torch.cuda.synchronize()
             outs.append(out.cpu())
         assert torch.isfinite(outs[0]).all()
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[3])
+        # GEMM epilogue variants (16-bit output with a 16-bit residual, fp32 output with an fp32 residual, ragged N % 8 == 0)
+        for (M, N, K, c_f32) in [(1000, 264, 192, 0), (3000, 512, 128, 1)]:
+            a = dev(torch.randn(M, K, generator=g).half())
+            wt = dev((torch.randn(N, K, generator=g) / K ** 0.5).half())
+            bias = dev(torch.randn(N, generator=g))
+            res = torch.randn(M, N, generator=g)
+            res = dev(res if c_f32 else res.half())
+            outs = []
+            for mask in (0, 4096):
+                check(lib, lib.t2p_debug_set(1, mask))
+                out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.float32 if c_f32 else torch.float16)
+                fn = lib.t2p_op_gemm if c_f32 else lib.t2p_op_gemm_r16
+                check(lib, fn(2, P(a), 0, P(wt), P(out), c_f32, M, N, K, K, K, N, P(bias), P(res), 0.5, None))
+                torch.cuda.synchronize()
+                outs.append(out.cpu())
+            assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1]), (M, N, K, c_f32)
     finally:
         lib.t2p_debug_set(1, 0)
         lib.t2p_debug_set(2, 0)

@@ -95,6 +95,21 @@ def lib_path() -> str:
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)   # t2p_allreduce_fn
 
 
+def load_ablation():
+    """Measurement tools only: the -DT2P_ABLATION build (a separate file; results can be WRONG by design)."""
+    global _lib
+    if _lib is not None:
+        raise T2PError("load_ablation() must come before any other use of the library")
+    lib = C.CDLL(_build.build(verbose=False, ablation=True))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    assert lib.t2p_built_with_ablation() == 1
+    _lib = lib
+    return lib
+
+
 def load(build_if_missing: bool = True):
     """dlopen libt2p_hip.so, building it first when it is missing or was built from other sources than the
     ones in the tree (content hash, text2protein_amd/build.py).  A stale library is never loaded: if the

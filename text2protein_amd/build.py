@@ -10,7 +10,9 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libt2p_hip.so")
+LIB_ABLATION = os.path.join(CSRC, "libt2p_hip_ablation.so")   # measurement builds only (tools/bench_conv.py --ablation)
 SOURCES = ["gemm.hip", "kernels.hip", "attention.hip", "engine.cpp", "capi.cpp"]
+GEMM_PARTS = 7          # gemm.hip is compiled once per -DT2P_GEMM_PART=k: the LDS-DMA instantiations build in parallel
 HEADERS = ["t2p_common.h", "t2p_kernels.h", "engine.h", os.path.join("..", "..", "include", "t2p.h")]
 ARCH = "gfx950"
 
@@ -38,12 +40,16 @@ def source_hash(ablation: bool = False) -> str:
     return h.hexdigest()
 
 
-def built_hash() -> str:
+def _read(path) -> str:
     try:
-        with open(STAMP) as f:
+        with open(path) as f:
             return f.read().strip()
     except OSError:
         return ""
+
+
+def built_hash() -> str:
+    return _read(STAMP)
 
 
 def needs_build() -> bool:
@@ -51,7 +57,7 @@ def needs_build() -> bool:
     return not os.path.exists(LIB) or built_hash() != source_hash()
 
 
-def scratch_users(remarks: str, kernel_prefix: str = "gemm_dma_kernel"):
+def scratch_users(remarks: str, kernel_prefix: str = "_kernel"):
     """Kernels whose -Rpass-analysis=kernel-resource-usage remarks report scratch (private memory).
 
     The LDS-DMA GEMM keeps 128 accumulator registers per lane; if a loop over them is left rolled
@@ -71,22 +77,26 @@ def scratch_users(remarks: str, kernel_prefix: str = "gemm_dma_kernel"):
 def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> str:
     """Compile every HIP/C++ source for gfx950 and link the shared library; returns its path.
 
-    ``ablation`` adds -DT2P_ABLATION: the timing-only switches of the LDS-DMA GEMM that skip work (and so give
-    wrong results) exist in such a build only; its stamp never matches, so the next ordinary load rebuilds."""
-    if not force and not ablation and not needs_build():
-        return LIB
+    ``ablation`` adds -DT2P_ABLATION and writes a SEPARATE library (libt2p_hip_ablation.so): the timing-only
+    switches of the LDS-DMA GEMM that skip work (and so give wrong results) exist in that build only; the product
+    library is never built with it."""
+    lib, stamp = (LIB_ABLATION, LIB_ABLATION + ".srchash") if ablation else (LIB, STAMP)
+    if not force and os.path.exists(lib) and _read(stamp) == source_hash(ablation):
+        return lib
     hipcc = _hipcc()
     objs = []
     procs = []
     flags = FLAGS + (["-DT2P_ABLATION"] if ablation else [])
-    if os.path.exists(STAMP):
-        os.remove(STAMP)
-    for src in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+    if os.path.exists(stamp):
+        os.remove(stamp)
+    units = [(src, None) for src in SOURCES if src != "gemm.hip"] + [("gemm.hip", k) for k in range(GEMM_PARTS)]
+    for src, part in sorted(units, key=lambda u: u[1] is None):       # the long gemm.hip units first
+        stem = os.path.splitext(src)[0] + ("" if part is None else f"_part{part}") + ("_abl" if ablation else "")
+        obj = os.path.join(CSRC, stem + ".o")
         objs.append(obj)
         cmd = [hipcc, *flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
-        if src == "gemm.hip":
-            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        if part is not None:
+            cmd[1:1] = ["-Rpass-analysis=kernel-resource-usage", f"-DT2P_GEMM_PART={part}"]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -111,13 +121,17 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
             out = "\n".join(keep)
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    with open(STAMP, "w") as f:
-        f.write(("ablation:" if ablation else "") + source_hash(ablation) + "\n")
-    return LIB
+    # every kernel's host stub must be there (a template body the host pass rejects is dropped silently): dlopen it
+    r = subprocess.run([sys.executable, "-c", f"import ctypes; ctypes.CDLL({lib!r})"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"{lib} does not load:\n{r.stderr[-2000:]}")
+    with open(stamp, "w") as f:
+        f.write(source_hash(ablation) + "\n")
+    return lib
 
 
 if __name__ == "__main__":

@@ -386,10 +386,11 @@ int t2p_debug_set(int key, int value) {
   if (key == 13) { g_gn_small = value != 0; return T2P_OK; }
   if (key == 14) { g_lowp_residual = value != 0; return T2P_OK; }
   if (key == 15) { set_gemm_thin_conv(value != 0); return T2P_OK; }
+  if (key == 16) { set_gemm_conv_halo(value != 0); return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) {
 #ifndef T2P_ABLATION
-    if (value & ~(128 | 256)) {
+    if (value & ~(128 | 256 | 4096)) {
       set_last_error("ablation bits that skip work exist only in a -DT2P_ABLATION build");
       return T2P_ERR_INVALID;
     }

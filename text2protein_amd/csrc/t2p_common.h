@@ -142,6 +142,7 @@ void set_gemm_splitk(bool on);
 void set_gemm_force_nsplit(int v);
 void set_gemm_midsplit(bool on);
 void set_gemm_thin_conv(bool on);
+void set_gemm_conv_halo(bool on);
 extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible
 extern bool g_lowp_h1;         // engine: block-internal conv0 output stored in the compute dtype
 extern bool g_lowp_residual;   // engine: residual stream between blocks in the compute dtype (f16 mode)
