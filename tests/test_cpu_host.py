@@ -189,4 +189,5 @@ gemm.hip:2:1: remark: Function Name: _ZN3t2p15gemm_dma_kernelIbEEv [-Rpass-analy
 gemm.hip:2:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]
 gemm.hip:3:1: remark: Function Name: _ZN3t2p11gemm_kernelIfEEv [-Rpass-analysis=kernel-resource-usage]
 gemm.hip:3:1: remark:     ScratchSize [bytes/lane]: 16 [-Rpass-analysis=kernel-resource-usage]"""
-    assert scratch_users(remarks) == [("_ZN3t2p15gemm_dma_kernelIaEEv", 544)]
+    assert scratch_users(remarks) == [("_ZN3t2p15gemm_dma_kernelIaEEv", 544), ("_ZN3t2p11gemm_kernelIfEEv", 16)]
+    assert scratch_users(remarks, "gemm_dma_kernel") == [("_ZN3t2p15gemm_dma_kernelIaEEv", 544)]

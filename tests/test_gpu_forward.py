@@ -101,3 +101,31 @@ def test_head_conv_thin_kernel_matches_gemm_path(dtype):
     err = rel_l2(b, a)
     print(f"thin head conv vs GEMM head conv ({dtype}): rel-L2 = {err:.3e}")
     assert err < 5e-6      # (bit-identical in practice: same K order, fp32 accumulation)
+
+
+def test_gn_apply_16byte_kernel_is_bit_identical():
+    """GroupNorm apply on 16-bit maps: the 16-byte / 4-pixels-in-flight kernel (plan switch 17) against the 8-byte one --
+    the same arithmetic per element, so the whole score must be bit-identical (f16 engine, maps of 32^2 and 16^2,
+    64 .. 192 channels incl. the two-source concat inputs of the up path)."""
+    from text2protein_amd import _lib, synth
+    from helpers import cfg_smallC
+    lib = _lib.load()
+    cfg = cfg_smallC()
+    m = make_model(cfg, 5, "f16")
+    B = 3
+    L = cfg.data.max_res_num
+    x = (torch.from_numpy(synth.normal(8, "x", B * 5 * L * L).reshape(B, 5, L, L)) * 10.0).cuda()
+    ctx = synth.synth_context(B, 7, cfg.model.context_dim, 2).cuda()
+    labels = torch.tensor([0, 4, 9]).cuda()
+    try:
+        lib.t2p_debug_set(17, 0)
+        a = m(x, labels, ctx).cpu()
+        lib.t2p_debug_set(17, 1)
+        lib.t2p_debug_set(18, 0)
+        b = m(x, labels, ctx).cpu()
+        lib.t2p_debug_set(18, 1)       # + the statistics folded inside the apply kernel (same summation order as the finalize kernel)
+        c = m(x, labels, ctx).cpu()
+    finally:
+        lib.t2p_debug_set(17, 1)
+        lib.t2p_debug_set(18, 1)
+    assert torch.isfinite(b).all() and torch.equal(a, b) and torch.equal(a, c)

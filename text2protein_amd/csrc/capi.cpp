@@ -387,6 +387,8 @@ int t2p_debug_set(int key, int value) {
   if (key == 14) { g_lowp_residual = value != 0; return T2P_OK; }
   if (key == 15) { set_gemm_thin_conv(value != 0); return T2P_OK; }
   if (key == 16) { set_gemm_conv_halo(value != 0); return T2P_OK; }
+  if (key == 17) { g_gn_apply16 = value != 0; return T2P_OK; }
+  if (key == 18) { g_gn_fuse_finalize = value != 0; return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) {
 #ifndef T2P_ABLATION

@@ -199,6 +199,16 @@ __device__ inline float silu_fast(float x) { return x * __frcp_rn(1.f + __expf(-
 // (rstd*gamma, beta - mean*rstd*gamma) are computed once, then it walks output pixels with 32-bit
 // indexing; consecutive lanes cover consecutive channels (coalesced 16-byte loads, 8/16-byte stores).
 static constexpr int GNA_PIX_PER_BLOCK = 64;
+bool g_gn_apply16 = true;     // 16-bit GroupNorm apply with 16-byte accesses (plan switch 17)
+bool g_gn_fuse_finalize = false;   // ... folding the producing GEMM's column sums itself on maps of <= 1024 pixels (plan switch 18;
+                                  // measured SLOWER than the separate finalize launch: +1.6 ms per PC step at cfg2, off by default)
+
+// true when launch_gn_apply(a) with a.cs0 set (and a.stats null) folds the statistics in the apply kernel
+bool gn_apply_fuses_finalize(const GroupNormApplyArgs& a) {
+  const int C = a.C0 + a.C1, HW = a.H * a.W;
+  return g_gn_apply16 && g_gn_fuse_finalize && a.x0_lowp && a.dtype != DT_F32 && !a.down && !a.raw_out && a.C0 % 8 == 0 && a.C1 % 8 == 0 &&
+         C >= 64 && C <= 2048 && 256 % (C / 8) == 0 && a.G <= 32 && HW % 64 == 0 && HW <= 1024;
+}
 
 template <typename TO, typename TI>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormApplyArgs a, int pix_per_block) {
@@ -254,6 +264,83 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormApplyArgs a, int
   }
 }
 
+
+// 16-bit in, 16-bit out, full resolution (the hot GroupNorm of f16 mode): a thread keeps 8 channels (16-byte loads and
+// stores) and has the rows of 4 pixels in flight at once -- the pass is a pure HBM round trip, so bytes in flight per CU
+// are what sets its rate (4.0 TB/s with 8-byte accesses and 2 pixels in flight at 128 channels; see profiles/README.md)
+// FIN: the statistics arrive as the producing GEMM's per-64-row column sums (a.cs0 / a.cs1) and every block folds its
+// sample's groups itself (same summation order as gn_finalize_cols_kernel, so the same bits) instead of a separate
+// finalize launch -- for maps of <= 1024 pixels, where that launch costs more than the few KiB of L2 reads per block
+template <typename T, bool FIN>
+__global__ __launch_bounds__(256) void gn_apply16_kernel(GroupNormApplyArgs a, int pix_per_block) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  __shared__ float sstat[FIN ? 64 : 1];
+  const int C = a.C0 + a.C1;
+  const int HW = a.H * a.W;
+  const int b = blockIdx.y;
+  if constexpr (FIN) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cpg = C / a.G, nchunk = HW >> 6, total = nchunk * cpg;
+    for (int g = wave; g < a.G; g += 4) {
+      double s = 0, q = 0;
+      for (int i = lane; i < total; i += 64) {
+        const int ch = i / cpg, c = g * cpg + (i - ch * cpg);
+        const float* src = c < a.C0 ? a.cs0 + ((long)(b * nchunk + ch) * a.C0 + c) * 2 : a.cs1 + ((long)(b * nchunk + ch) * a.C1 + (c - a.C0)) * 2;
+        s += src[0];
+        q += src[1];
+      }
+      s = wave_sum_d(s);
+      q = wave_sum_d(q);
+      if (lane == 0) {
+        const double n = (double)HW * cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0) var = 0;
+        sstat[2 * g] = (float)mean;
+        sstat[2 * g + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+      }
+    }
+    __syncthreads();
+  }
+  const int nvec = C >> 3;                       // threads per pixel (C <= 2048)
+  const int ppi = 256 / nvec;                    // pixels per block iteration
+  const int tid = threadIdx.x;
+  if (tid >= ppi * nvec) return;                 // (after the block-wide barrier of the FIN prologue)
+  const int v = tid % nvec, po = tid / nvec;
+  const int c = v * 8;
+  const int cpg = C / a.G;
+  const T* src; int ld, cc;
+  if (c < a.C0) { src = (const T*)a.x0; ld = a.C0; cc = c; } else { src = (const T*)a.x1; ld = a.C1; cc = c - a.C0; }
+  src += (long)b * HW * ld + cc;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float* st = FIN ? sstat + 2 * ((c + k) / cpg) : a.stats + ((long)b * a.G + (c + k) / cpg) * 2;
+    sc[k] = st[1] * a.gamma[c + k];
+    sh[k] = a.beta[c + k] - st[0] * sc[k];
+  }
+  T* out = (T*)a.out + (long)b * HW * C + c;
+  const int p_lo = blockIdx.x * pix_per_block, p_hi = min(HW, p_lo + pix_per_block);
+  auto apply = [&](u4 raw, int p) {
+    union { u4 u; T e[8]; } in, o;
+    in.u = raw;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float y = to_f32(in.e[k]) * sc[k] + sh[k];
+      if (a.silu) y = silu_fast(y);
+      o.e[k] = from_f32<T>(y);
+    }
+    *(u4*)(out + (long)p * C) = o.u;
+  };
+  int p = p_lo + po;
+  for (; p + 3 * ppi < p_hi; p += 4 * ppi) {
+    const u4 r0 = *(const u4*)(src + (long)p * ld), r1 = *(const u4*)(src + (long)(p + ppi) * ld);
+    const u4 r2 = *(const u4*)(src + (long)(p + 2 * ppi) * ld), r3 = *(const u4*)(src + (long)(p + 3 * ppi) * ld);
+    apply(r0, p); apply(r1, p + ppi); apply(r2, p + 2 * ppi); apply(r3, p + 3 * ppi);
+  }
+  for (; p < p_hi; p += ppi) apply(*(const u4*)(src + (long)p * ld), p);
+}
+
 static inline int ew_grid(long total, int block = 256) {
   long g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
@@ -261,7 +348,7 @@ static inline int ew_grid(long total, int block = 256) {
 
 int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s) {
   const int C = a.C0 + a.C1;
-  T2P_REQUIRE(a.x0 && a.stats && a.gamma && a.beta && a.out, "null pointer");
+  T2P_REQUIRE(a.x0 && (a.stats || a.cs0) && a.gamma && a.beta && a.out, "null pointer");
   T2P_REQUIRE(a.C0 % 4 == 0 && a.C1 % 4 == 0 && C % a.G == 0, "channel constraints");
   T2P_REQUIRE(!a.down || (a.H % 2 == 0 && a.W % 2 == 0), "down-sampling needs even H, W");
   T2P_REQUIRE(!(a.down && a.raw_out), "raw copy is not produced together with down-sampling");
@@ -275,6 +362,24 @@ int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s) {
   if (ppi > 1) ppb = (ppb + ppi - 1) / ppi * ppi;
   dim3 grid((HWo + ppb - 1) / ppb, a.B, zb);
   T2P_REQUIRE(!a.x0_lowp || a.dtype != DT_F32, "16-bit GroupNorm input needs a 16-bit dtype (both sources are then 16-bit)");
+  if (g_gn_apply16 && a.x0_lowp && !a.down && !a.raw_out && a.C0 % 8 == 0 && a.C1 % 8 == 0 && C >= 64 && C <= 2048 && 256 % (C / 8) == 0) {
+    const int ppi8 = 256 / (C / 8);
+    long want8 = ((long)HWo * a.B + 2047) / 2048;
+    int ppb8 = (int)std::min<long>(GNA_PIX_PER_BLOCK, std::max<long>(want8, ppi8));
+    ppb8 = (ppb8 + ppi8 - 1) / ppi8 * ppi8;
+    dim3 grid8((HWo + ppb8 - 1) / ppb8, a.B, 1);
+    if (a.cs0) {
+      T2P_REQUIRE(a.G <= 32 && HWo % 64 == 0, "fused GroupNorm finalize: <= 32 groups, 64-row chunks");
+      if (a.dtype == DT_BF16) hipLaunchKernelGGL((gn_apply16_kernel<bf16_t, true>), grid8, dim3(256), 0, s, a, ppb8);
+      else hipLaunchKernelGGL((gn_apply16_kernel<f16_t, true>), grid8, dim3(256), 0, s, a, ppb8);
+    } else {
+      if (a.dtype == DT_BF16) hipLaunchKernelGGL((gn_apply16_kernel<bf16_t, false>), grid8, dim3(256), 0, s, a, ppb8);
+      else hipLaunchKernelGGL((gn_apply16_kernel<f16_t, false>), grid8, dim3(256), 0, s, a, ppb8);
+    }
+    T2P_HIP_CHECK(hipGetLastError());
+    return T2P_OK;
+  }
+  T2P_REQUIRE(a.stats, "this GroupNorm apply kernel needs finalized statistics");
   switch (a.dtype) {
     case DT_F32: hipLaunchKernelGGL((gn_apply_kernel<float, float>), grid, dim3(256), 0, s, a, ppb); break;
     case DT_BF16:
