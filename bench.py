@@ -58,6 +58,7 @@ def parse():
                     help="replay each PC step from a captured hipGraph instead of launching its kernels one by one")
     ap.add_argument("--plan", default="", help="A/B measurements: 'key=value,...' plan switches of t2p_debug_set "
                     "(include/t2p.h: tile geometry, split-K, individual fusions; all produce correct results)")
+    ap.add_argument("--lib", default="", help="A/B measurements: load this libt2p_hip.so (built from another revision)")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 engine's line (rank 0, N = 1)")
     ap.add_argument("--f32-steps", type=int, default=2)
     return ap.parse_args()
@@ -111,6 +112,9 @@ def main():
     N = cfg.model.num_scales
     C_, L = cfg.data.num_channels, cfg.data.max_res_num
 
+    if args.lib:
+        from text2protein_amd import _lib as _L
+        _L.load_path(args.lib)
     set_plan_switches(args.plan)
     t_setup = time.perf_counter()
     sd = synth.synth_state_dict(cfg, seed=0)                 # same weights on every rank (replicated model)

@@ -95,6 +95,20 @@ def lib_path() -> str:
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)   # t2p_allreduce_fn
 
 
+def load_path(path):
+    """Measurement tools only (bench.py --lib): dlopen a library built from another revision, for A/B runs inside one call."""
+    global _lib
+    if _lib is not None:
+        raise T2PError("load_path() must come before any other use of the library")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
 def load_ablation():
     """Measurement tools only: the -DT2P_ABLATION build (a separate file; results can be WRONG by design)."""
     global _lib
