@@ -198,6 +198,9 @@ def main():
         dom, dom_name = (C.c_double * 4)(), C.create_string_buffer(256)
         check(lib.t2p_profile_dominant(dom, dom_name, 256))
         dom_ms, dom_fl, dom_n, dom_bytes = list(dom)
+        att = (C.c_double * 3)()
+        check(lib.t2p_profile_attention(att))
+        att_ms, att_fl, att_n = list(att)
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         if conv_n == 0:            # fp32 mode: every convolution runs on the register-staged exact-f32 kernel
             conv_ms, conv_fl, conv_n, c1_ms, c1_fl, c1_n = c1_ms, c1_fl, c1_n, 0.0, 0.0, 0.0
@@ -233,6 +236,9 @@ def main():
             "other_gemm": {"achieved": g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0, "launches_per_step": g_n / nprof,
                            "share_of_step_ms": g_ms / nprof, "frac": (g_fl / (g_ms * 1e-3) / 1e12 / peak) if g_ms > 0 else 0.0},
             "conv_on_v1_kernel": {"launches_per_step": c1_n / nprof, "share_of_step_ms": c1_ms / nprof},
+            # fused self / text cross-attention (attn_flash_kernel): the "attention roofline" of the north star
+            "attention": {"achieved": att_fl / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0, "launches_per_step": att_n / nprof,
+                          "share_of_step_ms": att_ms / nprof, "frac": (att_fl / (att_ms * 1e-3) / 1e12 / peak) if att_ms > 0 else 0.0},
         }
     if rank == 0 and world == 1 and not args.no_f32 and args.dtype != "f32":
         # the same workload on the exact-f32 engine (v_mfma_f32_32x32x2_f32: the reference's own arithmetic type),

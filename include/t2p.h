@@ -210,6 +210,9 @@ int t2p_profile_end(double* out9);
  * name = the kernel name as rocprofv3 reports it (no argument list), so that bench.py's live average launch duration
  * can be checked against profiles/<round>_kernel_stats.csv and the PMC traffic against the algorithmic bytes */
 int t2p_profile_dominant(double* out4, char* name, int name_len);
+/* after t2p_profile_end: the fused-attention launches of that region (CrossAttention.forward, model/attention.py:181-191,
+ * self and text cross-attention): out3 = {ms, flops (4 nq nk d per head), launches} */
+int t2p_profile_attention(double* out3);
 
 #ifdef __cplusplus
 }

@@ -54,7 +54,7 @@ struct FlashArgs {
 };
 
 template <typename TC, int D>
-__global__ __launch_bounds__(256) void attn_flash_kernel(const FlashArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_flash_kernel(const FlashArgs a) {
   constexpr int BKV = 64;
   constexpr int KS = D * 2 + 16;            // K tile row stride (bytes)
   constexpr int VS = BKV * 2 + 8;           // V^T tile row stride (bytes)
@@ -229,7 +229,17 @@ static int launch_flash_t(const FlashArgs& a, int B, int heads, hipStream_t s) {
   auto kern = attn_flash_kernel<TC, D>;
   T2P_TRY(ensure_dynamic_lds((const void*)kern, smem));
   dim3 grid((a.nq + 127) / 128, heads, B);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (prof_on()) {                     // bench.py roofline leg: HIP events on the launch stream
+    T2P_HIP_CHECK(hipEventCreate(&e0));
+    T2P_HIP_CHECK(hipEventCreate(&e1));
+    T2P_HIP_CHECK(hipEventRecord(e0, s));
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, a);
+  if (e0) {
+    T2P_HIP_CHECK(hipEventRecord(e1, s));
+    prof_attention(e0, e1, 4.0 * (double)a.nq * a.nk * D * heads * B);      // q k^T and p v
+  }
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }

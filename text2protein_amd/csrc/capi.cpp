@@ -435,6 +435,13 @@ int t2p_profile_end(double* out9) {
   API_END
 }
 
+int t2p_profile_attention(double* out3) {
+  API_BEGIN
+  T2P_REQUIRE(out3, "null argument");
+  return profile_attention(out3);
+  API_END
+}
+
 int t2p_profile_dominant(double* out4, char* name, int name_len) {
   API_BEGIN
   T2P_REQUIRE(out4 && name && name_len > 0, "null argument");

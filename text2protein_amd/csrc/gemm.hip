@@ -1541,7 +1541,19 @@ std::vector<ProfRec> g_prof;
 static std::string g_dom_name;
 static double g_dom[4] = {0, 0, 0, 0};
 
+// fused-attention launches of the profiled region (attention.hip reports them through prof_attention)
+static std::vector<ProfRec> g_prof_attn;
+static double g_attn[3] = {0, 0, 0};
+bool prof_on() { return g_prof_on; }
+void prof_attention(hipEvent_t a, hipEvent_t b, double flops) { g_prof_attn.push_back(ProfRec{a, b, flops, 3, nullptr, 0.0}); }
+int profile_attention(double out[3]) {
+  out[0] = g_attn[0]; out[1] = g_attn[1]; out[2] = g_attn[2];
+  return T2P_OK;
+}
+
 void profile_begin() {
+  for (ProfRec& r : g_prof_attn) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof_attn.clear();
   for (ProfRec& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   g_prof.clear();
   g_prof_on = true;
@@ -1565,6 +1577,15 @@ int profile_end(double out[3][3]) {
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
   g_prof.clear();
+  g_attn[0] = g_attn[1] = g_attn[2] = 0;
+  for (ProfRec& r : g_prof_attn) {
+    T2P_HIP_CHECK(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    T2P_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+    g_attn[0] += ms; g_attn[1] += r.flops; g_attn[2] += 1;
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  g_prof_attn.clear();
   g_dom_name.clear();
   g_dom[0] = g_dom[1] = g_dom[2] = g_dom[3] = 0;
   for (auto& kv : per)
