@@ -153,6 +153,10 @@ int t2p_op_groupnorm(const float* x0, const float* x1, int C0, int C1, int batch
                      void* stream);
 int t2p_op_layernorm(const float* x, const float* gamma, const float* beta, void* out, int dtype, int64_t rows,
                      int C, float eps, void* stream);
+/* the same on rows stored in the compute dtype (f16 / bf16), output in that dtype: the form the engine uses inside the
+ * transformer blocks in 16-bit modes (attention.py:203-205) */
+int t2p_op_layernorm16(const void* x16, const float* gamma, const float* beta, void* out16, int dtype, int64_t rows, int C,
+                       float eps, void* stream);
 int t2p_op_softmax(const float* S, int64_t lds, void* P, int64_t ldp, int dtype, int64_t rows, int n, float scale,
                    void* stream);
 int t2p_op_geglu(const float* u, void* out, int dtype, int64_t rows, int inner, void* stream);

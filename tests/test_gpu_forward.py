@@ -121,11 +121,7 @@ def test_gn_apply_16byte_kernel_is_bit_identical():
         lib.t2p_debug_set(17, 0)
         a = m(x, labels, ctx).cpu()
         lib.t2p_debug_set(17, 1)
-        lib.t2p_debug_set(18, 0)
         b = m(x, labels, ctx).cpu()
-        lib.t2p_debug_set(18, 1)       # + the statistics folded inside the apply kernel (same summation order as the finalize kernel)
-        c = m(x, labels, ctx).cpu()
     finally:
         lib.t2p_debug_set(17, 1)
-        lib.t2p_debug_set(18, 1)
-    assert torch.isfinite(b).all() and torch.equal(a, b) and torch.equal(a, c)
+    assert torch.isfinite(b).all() and torch.equal(a, b)

@@ -150,6 +150,32 @@ def test_layernorm(lib, rows, C):
     assert rel_l2(out.cpu(), ref) < 2e-6
 
 
+@pytest.mark.parametrize("C", [128, 512, 1024])
+def test_layernorm_16bit_rows(lib, C):
+    """LayerNorm on rows stored in 16 bits (the transformer blocks in f16 / bf16 mode); 512 / 1024 channels take the kernel
+    that keeps the row in registers (plan switch 20), which must agree with the three-pass kernel to output rounding."""
+    g = torch.Generator().manual_seed(C)
+    rows = 777
+    for dt in (1, 2):
+        td = TDT[dt]
+        x = (torch.randn(rows, C, generator=g) * 3.0 + 0.7).to(td)
+        ga, be = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        ref = F.layer_norm(x.double(), (C,), ga.double(), be.double(), 1e-5)
+        outs = []
+        try:
+            for sw in (1, 0):
+                check(lib, lib.t2p_debug_set(20, sw))
+                out = torch.full((rows, C), float("nan"), device="cuda", dtype=td)
+                check(lib, lib.t2p_op_layernorm16(P(dev(x)), P(dev(ga)), P(dev(be)), P(out), dt, rows, C, 1e-5, None))
+                torch.cuda.synchronize()
+                outs.append(out.cpu())
+        finally:
+            lib.t2p_debug_set(20, 1)
+        tol = 6e-3 if dt == 1 else 8e-4                    # one rounding of the output to bf16 / f16
+        assert rel_l2(outs[0].double(), ref) < tol and rel_l2(outs[1].double(), ref) < tol
+        assert rel_l2(outs[0].double(), outs[1].double()) < tol
+
+
 @pytest.mark.parametrize("rows,n", [(9, 3), (64, 64), (100, 1000), (5, 1500)])
 def test_softmax(lib, rows, n):
     g = torch.Generator().manual_seed(n)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "t2p_op_conv3x3": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2p_op_groupnorm": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
     "t2p_op_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp]),
+    "t2p_op_layernorm16": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp]),
     "t2p_op_softmax": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i, _f, _vp]),
     "t2p_op_geglu": (_i, [_vp, _vp, _i, _i64, _i, _vp]),
     "t2p_op_attention_ws": (_i64, [_i, _i, _i, _i, _i]),

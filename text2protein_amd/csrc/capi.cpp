@@ -251,6 +251,14 @@ int t2p_op_layernorm(const float* x, const float* gamma, const float* beta, void
   API_END
 }
 
+int t2p_op_layernorm16(const void* x16, const float* gamma, const float* beta, void* out16, int dtype, int64_t rows, int C,
+                       float eps, void* stream) {
+  API_BEGIN
+  T2P_REQUIRE(dtype == DT_F16 || dtype == DT_BF16, "t2p_op_layernorm16 takes a 16-bit dtype");
+  return launch_layernorm((const float*)x16, gamma, beta, out16, dtype, rows, C, eps, (hipStream_t)stream, 1);
+  API_END
+}
+
 int t2p_op_softmax(const float* S, int64_t lds, void* P, int64_t ldp, int dtype, int64_t rows, int n, float scale,
                    void* stream) {
   API_BEGIN
@@ -388,7 +396,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 15) { set_gemm_thin_conv(value != 0); return T2P_OK; }
   if (key == 16) { set_gemm_conv_halo(value != 0); return T2P_OK; }
   if (key == 17) { g_gn_apply16 = value != 0; return T2P_OK; }
-  if (key == 18) { g_gn_fuse_finalize = value != 0; return T2P_OK; }
+  if (key == 20) { g_layernorm16 = value != 0; return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) {
 #ifndef T2P_ABLATION

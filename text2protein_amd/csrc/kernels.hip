@@ -139,23 +139,39 @@ __global__ void gn_finalize_kernel(GroupNormArgs a, int nparts) {
 }
 
 // one wavefront per (sample, group): lanes stride over (chunk, channel) pairs, double accumulation
-__global__ __launch_bounds__(64) void gn_finalize_cols_kernel(const float* cs0, const float* cs1, int C0, int C1, int B, int HW,
-                                                              int G, float eps, float* stats) {
+__global__ __launch_bounds__(256) void gn_finalize_cols_kernel(const float* cs0, const float* cs1, int C0, int C1, int B, int HW,
+                                                               int G, float eps, float* stats) {
+  // one block per (sample, group): 256 threads walk the (chunk, channel-of-group) pairs with 4 independent loads in flight,
+  // accumulate in double, and are folded in a fixed order (wavefront shuffles, then the 4 wavefronts in LDS): reproducible
+  __shared__ double red[2][4];
   const int b = blockIdx.x / G, g = blockIdx.x - b * G;
   const int C = C0 + C1, cpg = C / G;
   const int nchunk = HW >> 6;
-  const int lane = threadIdx.x;
-  double s = 0, q = 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int total = nchunk * cpg;
-  for (int i = lane; i < total; i += 64) {
+  auto at = [&](int i) -> const float* {
     const int ch = i / cpg, c = g * cpg + (i - ch * cpg);
-    const float* src = c < C0 ? cs0 + ((long)(b * nchunk + ch) * C0 + c) * 2 : cs1 + ((long)(b * nchunk + ch) * C1 + (c - C0)) * 2;
-    s += src[0];
-    q += src[1];
+    return c < C0 ? cs0 + ((long)(b * nchunk + ch) * C0 + c) * 2 : cs1 + ((long)(b * nchunk + ch) * C1 + (c - C0)) * 2;
+  };
+  double s = 0, q = 0;
+  int i = tid;
+  for (; i + 768 < total; i += 1024) {
+    const float2 v0 = *(const float2*)at(i), v1 = *(const float2*)at(i + 256), v2 = *(const float2*)at(i + 512), v3 = *(const float2*)at(i + 768);
+    s += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+    q += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+  }
+  for (; i < total; i += 256) {
+    const float2 v = *(const float2*)at(i);
+    s += v.x;
+    q += v.y;
   }
   s = wave_sum_d(s);
   q = wave_sum_d(q);
-  if (lane == 0) {
+  if (lane == 0) { red[0][wave] = s; red[1][wave] = q; }
+  __syncthreads();
+  if (tid == 0) {
+    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const double n = (double)HW * cpg;
     const double mean = s / n;
     double var = q / n - mean * mean;
@@ -169,7 +185,7 @@ int launch_gn_finalize_cols(const float* cs0, const float* cs1, int C0, int C1, 
                             hipStream_t s) {
   T2P_REQUIRE(cs0 && stats && (C1 == 0) == (cs1 == nullptr), "gn_finalize_cols arguments");
   T2P_REQUIRE(HW % 64 == 0 && (C0 + C1) % G == 0, "gn_finalize_cols needs 64-row chunks aligned to samples");
-  hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(B * G), dim3(64), 0, s, cs0, cs1, C0, C1, B, HW, G, eps, stats);
+  hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(B * G), dim3(256), 0, s, cs0, cs1, C0, C1, B, HW, G, eps, stats);
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }
@@ -200,15 +216,6 @@ __device__ inline float silu_fast(float x) { return x * __frcp_rn(1.f + __expf(-
 // indexing; consecutive lanes cover consecutive channels (coalesced 16-byte loads, 8/16-byte stores).
 static constexpr int GNA_PIX_PER_BLOCK = 64;
 bool g_gn_apply16 = true;     // 16-bit GroupNorm apply with 16-byte accesses (plan switch 17)
-bool g_gn_fuse_finalize = false;   // ... folding the producing GEMM's column sums itself on maps of <= 1024 pixels (plan switch 18;
-                                  // measured SLOWER than the separate finalize launch: +1.6 ms per PC step at cfg2, off by default)
-
-// true when launch_gn_apply(a) with a.cs0 set (and a.stats null) folds the statistics in the apply kernel
-bool gn_apply_fuses_finalize(const GroupNormApplyArgs& a) {
-  const int C = a.C0 + a.C1, HW = a.H * a.W;
-  return g_gn_apply16 && g_gn_fuse_finalize && a.x0_lowp && a.dtype != DT_F32 && !a.down && !a.raw_out && a.C0 % 8 == 0 && a.C1 % 8 == 0 &&
-         C >= 64 && C <= 2048 && 256 % (C / 8) == 0 && a.G <= 32 && HW % 64 == 0 && HW <= 1024;
-}
 
 template <typename TO, typename TI>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormApplyArgs a, int pix_per_block) {
@@ -268,44 +275,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GroupNormApplyArgs a, int
 // 16-bit in, 16-bit out, full resolution (the hot GroupNorm of f16 mode): a thread keeps 8 channels (16-byte loads and
 // stores) and has the rows of 4 pixels in flight at once -- the pass is a pure HBM round trip, so bytes in flight per CU
 // are what sets its rate (4.0 TB/s with 8-byte accesses and 2 pixels in flight at 128 channels; see profiles/README.md)
-// FIN: the statistics arrive as the producing GEMM's per-64-row column sums (a.cs0 / a.cs1) and every block folds its
-// sample's groups itself (same summation order as gn_finalize_cols_kernel, so the same bits) instead of a separate
-// finalize launch -- for maps of <= 1024 pixels, where that launch costs more than the few KiB of L2 reads per block
-template <typename T, bool FIN>
+template <typename T>
 __global__ __launch_bounds__(256) void gn_apply16_kernel(GroupNormApplyArgs a, int pix_per_block) {
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
-  __shared__ float sstat[FIN ? 64 : 1];
   const int C = a.C0 + a.C1;
   const int HW = a.H * a.W;
   const int b = blockIdx.y;
-  if constexpr (FIN) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cpg = C / a.G, nchunk = HW >> 6, total = nchunk * cpg;
-    for (int g = wave; g < a.G; g += 4) {
-      double s = 0, q = 0;
-      for (int i = lane; i < total; i += 64) {
-        const int ch = i / cpg, c = g * cpg + (i - ch * cpg);
-        const float* src = c < a.C0 ? a.cs0 + ((long)(b * nchunk + ch) * a.C0 + c) * 2 : a.cs1 + ((long)(b * nchunk + ch) * a.C1 + (c - a.C0)) * 2;
-        s += src[0];
-        q += src[1];
-      }
-      s = wave_sum_d(s);
-      q = wave_sum_d(q);
-      if (lane == 0) {
-        const double n = (double)HW * cpg;
-        const double mean = s / n;
-        double var = q / n - mean * mean;
-        if (var < 0) var = 0;
-        sstat[2 * g] = (float)mean;
-        sstat[2 * g + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
-      }
-    }
-    __syncthreads();
-  }
   const int nvec = C >> 3;                       // threads per pixel (C <= 2048)
   const int ppi = 256 / nvec;                    // pixels per block iteration
   const int tid = threadIdx.x;
-  if (tid >= ppi * nvec) return;                 // (after the block-wide barrier of the FIN prologue)
+  if (tid >= ppi * nvec) return;
   const int v = tid % nvec, po = tid / nvec;
   const int c = v * 8;
   const int cpg = C / a.G;
@@ -315,7 +294,7 @@ __global__ __launch_bounds__(256) void gn_apply16_kernel(GroupNormApplyArgs a, i
   float sc[8], sh[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const float* st = FIN ? sstat + 2 * ((c + k) / cpg) : a.stats + ((long)b * a.G + (c + k) / cpg) * 2;
+    const float* st = a.stats + ((long)b * a.G + (c + k) / cpg) * 2;
     sc[k] = st[1] * a.gamma[c + k];
     sh[k] = a.beta[c + k] - st[0] * sc[k];
   }
@@ -348,7 +327,7 @@ static inline int ew_grid(long total, int block = 256) {
 
 int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s) {
   const int C = a.C0 + a.C1;
-  T2P_REQUIRE(a.x0 && (a.stats || a.cs0) && a.gamma && a.beta && a.out, "null pointer");
+  T2P_REQUIRE(a.x0 && a.stats && a.gamma && a.beta && a.out, "null pointer");
   T2P_REQUIRE(a.C0 % 4 == 0 && a.C1 % 4 == 0 && C % a.G == 0, "channel constraints");
   T2P_REQUIRE(!a.down || (a.H % 2 == 0 && a.W % 2 == 0), "down-sampling needs even H, W");
   T2P_REQUIRE(!(a.down && a.raw_out), "raw copy is not produced together with down-sampling");
@@ -368,18 +347,11 @@ int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s) {
     int ppb8 = (int)std::min<long>(GNA_PIX_PER_BLOCK, std::max<long>(want8, ppi8));
     ppb8 = (ppb8 + ppi8 - 1) / ppi8 * ppi8;
     dim3 grid8((HWo + ppb8 - 1) / ppb8, a.B, 1);
-    if (a.cs0) {
-      T2P_REQUIRE(a.G <= 32 && HWo % 64 == 0, "fused GroupNorm finalize: <= 32 groups, 64-row chunks");
-      if (a.dtype == DT_BF16) hipLaunchKernelGGL((gn_apply16_kernel<bf16_t, true>), grid8, dim3(256), 0, s, a, ppb8);
-      else hipLaunchKernelGGL((gn_apply16_kernel<f16_t, true>), grid8, dim3(256), 0, s, a, ppb8);
-    } else {
-      if (a.dtype == DT_BF16) hipLaunchKernelGGL((gn_apply16_kernel<bf16_t, false>), grid8, dim3(256), 0, s, a, ppb8);
-      else hipLaunchKernelGGL((gn_apply16_kernel<f16_t, false>), grid8, dim3(256), 0, s, a, ppb8);
-    }
+    if (a.dtype == DT_BF16) hipLaunchKernelGGL((gn_apply16_kernel<bf16_t>), grid8, dim3(256), 0, s, a, ppb8);
+    else hipLaunchKernelGGL((gn_apply16_kernel<f16_t>), grid8, dim3(256), 0, s, a, ppb8);
     T2P_HIP_CHECK(hipGetLastError());
     return T2P_OK;
   }
-  T2P_REQUIRE(a.stats, "this GroupNorm apply kernel needs finalized statistics");
   switch (a.dtype) {
     case DT_F32: hipLaunchKernelGGL((gn_apply_kernel<float, float>), grid, dim3(256), 0, s, a, ppb); break;
     case DT_BF16:
@@ -529,11 +501,66 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* x, const float
   }
 }
 
+// 16-bit in / out, C = 512 NV (512 or 1024 channels: the transformer widths at nf = 256): a wavefront owns a row, a lane
+// keeps its 8 NV elements in registers (one 16-byte load each), so the row is read once; two-pass mean / variance as above.
+bool g_layernorm16 = true;      // plan switch 20
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm16_kernel(const T* x, const float* gamma, const float* beta, T* out, long rows, float eps) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  constexpr int C = 512 * NV;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const T* xr = x + row * C + lane * 8;
+  float v[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    union { u4 u; T e[8]; } in;
+    in.u = *(const u4*)(xr + 512 * k);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[k][j] = to_f32(in.e[j]);
+    s += ((v[k][0] + v[k][1]) + (v[k][2] + v[k][3])) + ((v[k][4] + v[k][5]) + (v[k][6] + v[k][7]));
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[k][j] -= mean; }
+    q += ((v[k][0] * v[k][0] + v[k][1] * v[k][1]) + (v[k][2] * v[k][2] + v[k][3] * v[k][3])) +
+         ((v[k][4] * v[k][4] + v[k][5] * v[k][5]) + (v[k][6] * v[k][6] + v[k][7] * v[k][7]));
+  }
+  const float rstd = 1.f / sqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = 512 * k + lane * 8;
+    const float4 g0 = *(const float4*)(gamma + c), g1 = *(const float4*)(gamma + c + 4);
+    const float4 b0 = *(const float4*)(beta + c), b1 = *(const float4*)(beta + c + 4);
+    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    union { u4 u; T e[8]; } o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.e[j] = from_f32<T>(v[k][j] * rstd * gg[j] + bb[j]);
+    *(u4*)(out + row * C + c) = o.u;
+  }
+}
+
 int launch_layernorm(const float* x, const float* gamma, const float* beta, void* out, int dtype, long rows, int C,
                      float eps, hipStream_t s, int x_lowp) {
   T2P_REQUIRE(x && gamma && beta && out && C % 4 == 0 && rows > 0, "layernorm arguments");
   T2P_REQUIRE(!x_lowp || dtype != DT_F32, "16-bit LayerNorm input needs a 16-bit dtype");
   dim3 grid((unsigned)((rows + 3) / 4));
+  if (g_layernorm16 && x_lowp && dtype != DT_F32 && (C == 512 || C == 1024)) {
+    if (dtype == DT_F16) {
+      if (C == 512) hipLaunchKernelGGL((layernorm16_kernel<f16_t, 1>), grid, dim3(256), 0, s, (const f16_t*)x, gamma, beta, (f16_t*)out, rows, eps);
+      else hipLaunchKernelGGL((layernorm16_kernel<f16_t, 2>), grid, dim3(256), 0, s, (const f16_t*)x, gamma, beta, (f16_t*)out, rows, eps);
+    } else {
+      if (C == 512) hipLaunchKernelGGL((layernorm16_kernel<bf16_t, 1>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)out, rows, eps);
+      else hipLaunchKernelGGL((layernorm16_kernel<bf16_t, 2>), grid, dim3(256), 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)out, rows, eps);
+    }
+    T2P_HIP_CHECK(hipGetLastError());
+    return T2P_OK;
+  }
   switch (dtype) {
     case DT_F32: hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, dim3(256), 0, s, x, gamma, beta, (float*)out, rows, C, eps); break;
     case DT_BF16:

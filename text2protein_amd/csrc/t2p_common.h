@@ -146,7 +146,7 @@ void set_gemm_conv_halo(bool on);
 extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible
 extern bool g_lowp_h1;         // engine: block-internal conv0 output stored in the compute dtype
 extern bool g_lowp_residual;   // engine: residual stream between blocks in the compute dtype (f16 mode)
-extern bool g_gn_fuse_finalize;
+extern bool g_layernorm16;     // LayerNorm of 16-bit rows of 512 / 1024 channels: the row is read once (plan switch 20)
 extern bool g_gn_apply16;      // GroupNorm apply on 16-bit maps: 16-byte accesses, 4 pixels in flight
 extern bool g_gn_small;        // engine / op API: single-launch GroupNorm for maps of <= 64 pixels
 extern bool g_fuse_geglu;      // engine: GEGLU gating inside the ff1 GEMM epilogue

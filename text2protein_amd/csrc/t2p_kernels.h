@@ -27,8 +27,7 @@ int launch_gn_finalize_cols(const float* cs0, const float* cs1, int C0, int C1, 
 struct GroupNormApplyArgs {
   const float* x0 = nullptr; const float* x1 = nullptr;
   int C0 = 0, C1 = 0, B = 0, H = 0, W = 0, G = 0;
-  const float* stats = nullptr;       // [B][G][2] (mean, rstd) -- or, where gn_apply_fuses_finalize():
-  const float* cs0 = nullptr; const float* cs1 = nullptr;   // per-64-row column sums of the two sources (GemmParams::col_stats)
+  const float* stats = nullptr;       // [B][G][2]
   const float* gamma = nullptr; const float* beta = nullptr;
   int silu = 0;
   int down = 0;                        // 2x2 mean of the activated map (layers.py:185-188)
@@ -40,7 +39,6 @@ struct GroupNormApplyArgs {
   float eps = 0.f;                     // launch_gn_small only
 };
 int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s);
-bool gn_apply_fuses_finalize(const GroupNormApplyArgs& a);
 // statistics + normalisation (+SiLU, + raw copy) of a small map in ONE launch (no `stats` input, no `down`)
 bool gn_small_eligible(const GroupNormApplyArgs& a);
 int launch_gn_small(const GroupNormApplyArgs& a, hipStream_t s);
