@@ -1096,42 +1096,60 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
     b_off[j] = n < p.N ? (unsigned)((long)n * p.ldb * 2) + (unsigned)((ppos ^ ((r >> 1) & 7)) * 16) : DMA_OOB;
   }
 
-  auto issue = [&](int kl, int part) {   // part 0: A rows, 1: B rows, 2: both; kl counts from this block's first K-tile
-    unsigned char* sta = smem + (kl % NST) * ASTAGE;
-    unsigned char* stb = smem + BRING + (kl % NSTB) * BSTAGE;
-    const int kt = kt_lo + kl;
-    const int chunk = kt / TAPS;
-    const int tap = kt - chunk * TAPS;
-    const int c0 = chunk * BK;                         // channel base of this K-tile
-    int dy = 0, dx = 0;
-    if (MODE != 0) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
-    const bool second = c0 >= p.C0;                    // wave-uniform: C0 % 64 == 0
-    const int csrc = second ? c0 - p.C0 : c0;
-    const unsigned ld2 = second ? lda1_2 : lda0_2;
-    const __amdgpu_buffer_rsrc_t rA = make_rsrc(second ? (const void*)p.A1 : (const void*)A0p, second ? a1_bytes : a0_bytes);
-    const unsigned udelta = (unsigned)((dy * p.W + dx) * (int)ld2 + csrc * 2);   // wave-uniform
-    const unsigned tbit = 1u << tap;
-    if (part != 1)
+  // Issue-stream state (wave-uniform).  The A and the B stream are each issued strictly in K order, every K-tile once, so
+  // the (chunk, tap, ring stage) of a stream's next K-tile are carried along instead of being divided out of the K index at
+  // every issue: the scalar prelude of an issue is what the two waves of a SIMD cannot hide from each other.
+  int ia_chunk = kt_lo / TAPS, ia_tap = kt_lo - (kt_lo / TAPS) * TAPS, ia_st = 0;
+  int ia_dy = MODE != 0 ? ia_tap / 3 - 1 : 0, ia_dx = MODE != 0 ? ia_tap - (ia_tap / 3) * 3 - 1 : 0;
+  int ib_chunk = ia_chunk, ib_tap = ia_tap, ib_st = 0;
+  auto issue = [&](int /* kl: the streams keep their own position */, int part) {   // part 0: A rows, 1: B rows, 2: both
+    if (part != 1) {
+      unsigned char* sta = smem + ia_st * ASTAGE;
+      const int c0 = ia_chunk * BK;                      // channel base of this K-tile
+      const bool second = c0 >= p.C0;                    // wave-uniform: C0 % 64 == 0
+      const int csrc = second ? c0 - p.C0 : c0;
+      const unsigned ld2 = second ? lda1_2 : lda0_2;
+      const __amdgpu_buffer_rsrc_t rA = make_rsrc(second ? (const void*)p.A1 : (const void*)A0p, second ? a1_bytes : a0_bytes);
+      const unsigned udelta = (unsigned)((ia_dy * p.W + ia_dx) * (int)ld2 + csrc * 2);   // wave-uniform
 #pragma unroll
-    for (int j = 0; j < A_INSTR; ++j) {
-      const bool ok = (a_vm[j] & tbit) != 0;
-      unsigned voff;
-      if (MODE == 2) {
-        const int row = a_bb[j] + ((a_y[j] + dy) >> 1) * Ws + ((a_x[j] + dx) >> 1);
-        voff = (unsigned)row * ld2 + (unsigned)(csrc * 2) + a_off0[j];
-      } else {
-        voff = (second ? a_off1[j] : a_off0[j]) + udelta;
+      for (int j = 0; j < A_INSTR; ++j) {
+        unsigned voff;
+        if (MODE == 2) {
+          const int row = a_bb[j] + ((a_y[j] + ia_dy) >> 1) * Ws + ((a_x[j] + ia_dx) >> 1);
+          voff = (unsigned)row * ld2 + (unsigned)(csrc * 2) + a_off0[j];
+        } else {
+          voff = (second ? a_off1[j] : a_off0[j]) + udelta;
+        }
+        // tap validity: bit ia_tap of a_vm[j] spread over the word (v_bfe_i32), then offset-or-out-of-range in one v_bfi_b32
+        const unsigned m = (dbg & 64) ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)a_vm[j], (unsigned)ia_tap, 1u);
+        unsigned char* dst = sta + (wave * A_INSTR + j) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, T2P_LDS_PTR(dst), 16, (voff & m) | (DMA_OOB & ~m), 0, 0, 0);
       }
-      unsigned char* dst = sta + (wave * A_INSTR + j) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, T2P_LDS_PTR(dst), 16, (ok && !(dbg & 64)) ? voff : DMA_OOB, 0, 0, 0);
+      ia_st = ia_st + 1 == NST ? 0 : ia_st + 1;
+      if (TAPS == 1) {
+        ++ia_chunk;
+      } else {
+        ++ia_tap; ++ia_dx;
+        if (ia_dx > 1) { ia_dx = -1; ++ia_dy; }
+        if (ia_tap == TAPS) { ia_tap = 0; ++ia_chunk; ia_dy = -1; ia_dx = -1; }
+      }
     }
-    const unsigned kb = (unsigned)(((long)tap * Ctot + c0) * 2);
-    if (part != 0)
+    if (part != 0) {
+      unsigned char* stb = smem + BRING + ib_st * BSTAGE;
+      const unsigned kb = (unsigned)(((long)ib_tap * Ctot + ib_chunk * BK) * 2);
 #pragma unroll
-    for (int j = 0; j < B_INSTR; ++j) {
-      const unsigned voff = (dbg & 64) ? DMA_OOB : b_off[j] + kb;   // rows beyond N carry DMA_OOB: adding kb (< 2 GiB) keeps them out of range
-      unsigned char* dst = stb + (wave * B_INSTR + j) * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, T2P_LDS_PTR(dst), 16, voff, 0, 0, 0);
+      for (int j = 0; j < B_INSTR; ++j) {
+        const unsigned voff = (dbg & 64) ? DMA_OOB : b_off[j] + kb;   // rows beyond N carry DMA_OOB: adding kb (< 2 GiB) keeps them out of range
+        unsigned char* dst = stb + (wave * B_INSTR + j) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, T2P_LDS_PTR(dst), 16, voff, 0, 0, 0);
+      }
+      ib_st = ib_st + 1 == NSTB ? 0 : ib_st + 1;
+      if (TAPS == 1) {
+        ++ib_chunk;
+      } else {
+        ++ib_tap;
+        if (ib_tap == TAPS) { ib_tap = 0; ++ib_chunk; }
+      }
     }
   };
 
