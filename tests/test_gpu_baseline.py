@@ -199,3 +199,36 @@ def test_thousand_step_f16_within_tolerance(stem):
     print(f"{stem}: 1000 PC steps, f16 vs exact-f32 engine, final sample rel-L2 = {e:.3e}")
     _record(f"run1000_{stem}", {"f16_vs_f32_engine": e, "chains": B, "L": L, "N": N})
     assert e < F16_TOL
+
+
+def test_up_phase_convolution_matches_gather_form():
+    """The first convolution of an up-sampling block runs as four 2x2 phase convolutions on the source map (taps that read
+    the same source pixel summed on the host, plan switch 21) instead of a 3x3 gather from the half-resolution map: at the
+    benchmark batch of cfg3 (the plan selects it from 200 tiles on) both forms must reproduce the reference's samples."""
+    from text2protein_amd import _lib, synth
+    stem = "cond_length"
+    cfg, B0, T, chains = _cfg(stem)
+    g = load_golden("full_" + stem)
+    sd = synth.synth_state_dict(cfg, 0)
+    x, labels, ctx = full_inputs(cfg, B0, T)
+    xs = torch.from_numpy(synth.normal(79, "filler_x", chains * x[0].numel()).reshape(chains, *x.shape[1:])).cuda() * 20.0
+    cs = synth.synth_context(chains, T, cfg.model.context_dim, 80).cuda()
+    ls = (torch.arange(chains, device="cuda") * 29 + 5) % cfg.model.num_scales
+    for i, s in enumerate((3, chains - 2)):
+        xs[s], cs[s], ls[s] = x[i].cuda(), ctx[i].cuda(), labels[i].cuda()
+    lib = _lib.load()
+    m16 = _model(cfg, sd, "f16")
+    outs = {}
+    try:
+        for sw in (0, 1):
+            _lib.check(lib.t2p_debug_set(21, sw))
+            outs[sw] = m16(xs, ls, cs).cpu()
+    finally:
+        lib.t2p_debug_set(21, 1)
+    assert not torch.equal(outs[0], outs[1]), "the phase form did not run"
+    d = rel_l2(outs[1], outs[0])
+    print(f"phase form vs gather form of the up-sampling convolutions: rel-L2 = {d:.3e}")
+    assert d < 1e-3
+    for i, s in enumerate((3, chains - 2)):
+        for sw in (0, 1):
+            assert rel_l2(outs[sw][s], g["score"][i]) < F16_SCORE_TOL

@@ -397,6 +397,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 16) { set_gemm_conv_halo(value != 0); return T2P_OK; }
   if (key == 17) { g_gn_apply16 = value != 0; return T2P_OK; }
   if (key == 20) { g_layernorm16 = value != 0; return T2P_OK; }
+  if (key == 21) { set_gemm_up4(value != 0); return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) {
 #ifndef T2P_ABLATION

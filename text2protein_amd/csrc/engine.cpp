@@ -419,6 +419,27 @@ int Engine::finalize() {
       T2P_TRY(upload_norm(p + ".GroupNorm_0", ci, gn_groups(ci), &l.gn0));
       T2P_TRY(upload_norm(p + ".GroupNorm_1", co, gn_groups(co), &l.gn1));
       T2P_TRY(upload_linear(p + ".Conv_0.weight", p + ".Conv_0.bias", co, 9 * ci, &l.conv0, true));
+      if (l.up && cfg_.compute_dtype != DT_F32) {
+        // conv0 of an up block reads the 2x nearest-up-sampled map (layers.py:306-308): output phase (py, px) of pixel
+        // (2 yl + py, 2 xl + px) sees source pixel yl + floor((py + kh - 1) / 2) for kernel row kh, i.e. two source rows per
+        // phase; the taps that read the same source pixel are summed here (in fp32, before the one rounding to the compute
+        // dtype): four 2x2 convolutions on the source map with 4 / 9 of the multiplications
+        const HostTensor* w = host(p + ".Conv_0.weight", {co, ci, 3, 3});
+        if (!w) return T2P_ERR_STATE;
+        std::vector<float> w4((size_t)4 * co * 4 * ci, 0.f);
+        auto fl2 = [](int f) { return f >= 0 ? f / 2 : -((-f + 1) / 2); };
+        for (int py = 0; py < 2; ++py)
+          for (int px = 0; px < 2; ++px)
+            for (int kh = 0; kh < 3; ++kh)
+              for (int kw = 0; kw < 3; ++kw) {
+                const int ty = fl2(py + kh - 1) + 1 - py, tx = fl2(px + kw - 1) + 1 - px;     // 0 or 1
+                const size_t ph = (size_t)(py * 2 + px), tap = (size_t)(ty * 2 + tx);
+                for (int n = 0; n < co; ++n)
+                  for (int c = 0; c < ci; ++c)
+                    w4[((ph * co + n) * 4 + tap) * ci + c] += w->data[(((size_t)n * ci + c) * 3 + kh) * 3 + kw];
+              }
+        T2P_TRY(upload_matrix(pool_, w4, cfg_.compute_dtype, &l.conv0_up4));
+      }
       T2P_TRY(upload_linear(p + ".Conv_1.weight", p + ".Conv_1.bias", co, 9 * co, &l.conv1, true));
       if (l.has_conv2) T2P_TRY(upload_linear(p + ".Conv_2.weight", p + ".Conv_2.bias", co, ci, &l.conv2));
       const HostTensor* w = host(p + ".Dense_0.weight", {co, td});
@@ -622,6 +643,7 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     p.dtype = dt; p.A0 = a0; p.a_f32 = dt == DT_F32; p.C0 = Cin; p.lda0 = Cin;
     p.taps = 9; p.H = Ho; p.W = Wo; p.a_up = L.up;
     p.Bw = L.conv0.w; p.ldb = L.conv0.K; p.M = (int)rows_out; p.N = Cout;
+    if (L.up && L.conv0_up4 && !skip) { p.Bw4 = L.conv0_up4; p.ldb4 = 4L * Cin; }
     p.bias_n = L.conv0.b; p.bias_bn = tb_ + L.temb_off; p.ld_bn = tb_ld_; p.rows_per_batch = Ho * Wo;
     p.C = h1; p.c_f32 = 1; p.ldc = Cout;
     // h1 is read once more, by GroupNorm_1 only: when its statistics come out of this epilogue

@@ -55,6 +55,7 @@ struct Layer {
   // res
   DevNorm gn0, gn1;
   DevLinear conv0, conv1, conv2;
+  void* conv0_up4 = nullptr;   // up blocks, 16-bit modes: conv0 as four 2x2 phase convolutions, [4][Cout][4 * Cin] (GemmParams::Bw4)
   bool has_conv2 = false;
   int temb_off = 0;
   // attn (AttnBlockpp): NIN_0|NIN_1 stacked, NIN_2, NIN_3

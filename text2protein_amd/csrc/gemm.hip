@@ -147,7 +147,7 @@ struct DmaPlan { int geom, nsplit; };
 extern bool g_prof_on;
 extern std::vector<ProfRec> g_prof;
 extern int g_dma_ring, g_dbg;
-extern bool g_conv_halo;
+extern bool g_conv_halo, g_up4;
 DmaPlan dma_plan(const GemmParams& p);
 int launch_splitk_reduce(const GemmParams& p, int nsplit, hipStream_t stream);
 template <typename TC, int MODE> int launch_dma_mode(const GemmParams& p, hipStream_t stream);
@@ -796,6 +796,10 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
   const __amdgpu_buffer_rsrc_t rR = make_rsrc(R ? (const void*)R : (const void*)p.C, (int)r_bytes);
 
   const int row_w = m0 + wm * (BM / WM);                 // first row of the wave tile (128 rows = 8 tiles of 16)
+  // up_phase (MODE 3): rows are pixels of the half-resolution map; row (b, yl, xl) is stored at output pixel (b, 2 yl + py, 2 xl + px)
+  const int upp = p.up_phase;
+  const int Mrows = upp ? p.M >> 2 : p.M;
+  const int Wl = p.W >> 1, HWl = (p.H >> 1) * (p.W >> 1);
   const int col0 = n0 + wn * (BN / WN) + 8 * g4;         // this lane's channels: [col0, col0 + 8) and [col0 + 32, col0 + 40)
   const bool ok0 = col0 < p.N, ok1 = col0 + 32 < p.N;    // N % 8 == 0: a group of 8 channels is in or out as a whole
   // per-channel constants: bias_n + the time-embedding bias of the tile's first sample
@@ -804,7 +808,7 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
   for (int k = 0; k < 16; ++k) bs[k] = 0.f;
   const int rpb = p.rows_per_batch;
   const bool need_b = p.bias_bn || p.r_up;
-  const int b_first = need_b ? m0 / rpb : 0;
+  const int b_first = upp ? m0 / HWl : (need_b ? m0 / rpb : 0);
   if (!ws) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -835,7 +839,13 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
     row = row_w + 16 * i + l16;
     bsel = 0;
     rrow = (unsigned)row;
-    if (need_b) {
+    if (upp) {                                            // wave-uniform; Wl % 16 == 0: a tile's 16 rows share (b, yl)
+      const int rt = row_w + 16 * i;
+      const int bidx = rt / HWl, rem = rt - bidx * HWl, yl = rem / Wl, xl = rem - yl * Wl;
+      bsel = bidx - (m0 / HWl);
+      row = rt < Mrows ? (bidx * p.H + 2 * yl + ((upp - 1) >> 1)) * p.W + 2 * (xl + l16) + ((upp - 1) & 1) : p.M;
+      rrow = (unsigned)row;
+    } else if (need_b) {
       const int rt = row_w + 16 * i;                      // wave-uniform: the 16 rows of a tile lie in one sample (rpb % 16 == 0)
       const int bidx = rt / rpb;
       bsel = bidx - b_first;                              // 0 inside the tile's first sample
@@ -941,11 +951,16 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
     if (!p.col_stats || ws) return;
 #pragma unroll
     for (int k = 0; k < 16; ++k) { cs[k] = row16_sum(cs[k]); cq[k] = row16_sum(cq[k]); }
-    if (l16 == 0 && chunk_row < p.M) {
+    if (l16 == 0 && chunk_row < Mrows) {
+      long chunk = chunk_row >> 6;
+      if (upp) {            // the consumer sums the HW / 64 chunks of a sample: a phase fills its quarter of each sample's range
+        const int bidx = chunk_row / HWl;
+        chunk = (long)bidx * ((p.H * p.W) >> 6) + (long)(upp - 1) * (HWl >> 6) + ((chunk_row - bidx * HWl) >> 6);
+      }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if (h ? ok1 : ok0) {
-          float* dst = p.col_stats + ((long)(chunk_row >> 6) * p.N + col0 + 32 * h) * 2;
+          float* dst = p.col_stats + (chunk * p.N + col0 + 32 * h) * 2;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             *(float4*)(dst + 4 * q) = make_float4(cs[8 * h + 2 * q], cq[8 * h + 2 * q], cs[8 * h + 2 * q + 1], cq[8 * h + 2 * q + 1]);
@@ -1010,7 +1025,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;  // DMA instructions per wave per K-tile (8 rows each)
   constexpr int ASTAGE = BM * 128, BSTAGE = BN * 128;
   constexpr int BRING = NST * ASTAGE;                            // byte offset of the B ring
-  constexpr int TAPS = MODE == 0 ? 1 : 9;
+  constexpr int TAPS = MODE == 0 ? 1 : (MODE == 3 ? 4 : 9);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
@@ -1038,7 +1053,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   const int kt_lo = (int)((long)nk_all * ks / nsplit), kt_hi = (int)((long)nk_all * (ks + 1) / nsplit);
   const int nk = kt_hi - kt_lo;
   const int HW = p.H * p.W;
-  const int Hs = MODE == 2 ? (p.H >> 1) : p.H, Ws = MODE == 2 ? (p.W >> 1) : p.W;
+  const int Hs = MODE >= 2 ? (p.H >> 1) : p.H, Ws = MODE >= 2 ? (p.W >> 1) : p.W;
+  // MODE 3: one output phase (py, px) of a 3x3 convolution on a 2x nearest-up-sampled map = a 2x2 convolution on the
+  // half-resolution map (the taps that read the same source pixel are summed into one weight on the host): rows are the
+  // M / 4 source pixels, tap (ty, tx) reads pixel (yl + ty - 1 + py, xl + tx - 1 + px), the epilogue scatters row
+  // (b, yl, xl) to output pixel (b, 2 yl + py, 2 xl + px).  4 / 9 of the multiplications of the gather form (MODE 2).
+  const int up_py = MODE == 3 ? ((p.up_phase - 1) >> 1) : 0, up_px = MODE == 3 ? ((p.up_phase - 1) & 1) : 0;
+  const int Mq = MODE == 3 ? p.M >> 2 : p.M;            // rows of this launch
+  const int HWq = MODE == 3 ? Hs * Ws : HW, Wq = MODE == 3 ? Ws : p.W, Hq = MODE == 3 ? Hs : p.H;
 
   // buffer descriptors: whole operand in range, everything else reads as zero.  Built from
   // readfirstlane'd scalars so that hipcc keeps them in SGPRs (no waterfall loop around the DMA).
@@ -1066,14 +1088,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
     unsigned vm = 0;
     int y = 0, x = 0, b = 0;
     if (MODE != 0) {
-      b = m / HW;
-      const int rem = m - b * HW;
-      y = rem / p.W;
-      x = rem - y * p.W;
+      b = m / HWq;
+      const int rem = m - b * HWq;
+      y = rem / Wq;
+      x = rem - y * Wq;
     }
-    if (m < p.M) {
+    if (m < Mq) {
       if (MODE == 0) {
         vm = 1;
+      } else if (MODE == 3) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int sy = y + (t >> 1) - 1 + up_py, sx = x + (t & 1) - 1 + up_px;
+          if (sy >= 0 && sy < Hq && sx >= 0 && sx < Wq) vm |= 1u << t;
+        }
       } else {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -1100,7 +1128,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   // the (chunk, tap, ring stage) of a stream's next K-tile are carried along instead of being divided out of the K index at
   // every issue: the scalar prelude of an issue is what the two waves of a SIMD cannot hide from each other.
   int ia_chunk = kt_lo / TAPS, ia_tap = kt_lo - (kt_lo / TAPS) * TAPS, ia_st = 0;
-  int ia_dy = MODE != 0 ? ia_tap / 3 - 1 : 0, ia_dx = MODE != 0 ? ia_tap - (ia_tap / 3) * 3 - 1 : 0;
+  int ia_dy = MODE == 3 ? (ia_tap >> 1) - 1 + up_py : (MODE != 0 ? ia_tap / 3 - 1 : 0);
+  int ia_dx = MODE == 3 ? (ia_tap & 1) - 1 + up_px : (MODE != 0 ? ia_tap - (ia_tap / 3) * 3 - 1 : 0);
   int ib_chunk = ia_chunk, ib_tap = ia_tap, ib_st = 0;
   auto issue = [&](int /* kl: the streams keep their own position */, int part) {   // part 0: A rows, 1: B rows, 2: both
     if (part != 1) {
@@ -1110,7 +1139,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
       const int csrc = second ? c0 - p.C0 : c0;
       const unsigned ld2 = second ? lda1_2 : lda0_2;
       const __amdgpu_buffer_rsrc_t rA = make_rsrc(second ? (const void*)p.A1 : (const void*)A0p, second ? a1_bytes : a0_bytes);
-      const unsigned udelta = (unsigned)((ia_dy * p.W + ia_dx) * (int)ld2 + csrc * 2);   // wave-uniform
+      const unsigned udelta = (unsigned)((ia_dy * Wq + ia_dx) * (int)ld2 + csrc * 2);   // wave-uniform
 #pragma unroll
       for (int j = 0; j < A_INSTR; ++j) {
         unsigned voff;
@@ -1128,6 +1157,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
       ia_st = ia_st + 1 == NST ? 0 : ia_st + 1;
       if (TAPS == 1) {
         ++ia_chunk;
+      } else if (MODE == 3) {
+        ++ia_tap;
+        if (ia_tap == TAPS) { ia_tap = 0; ++ia_chunk; }
+        ia_dy = (ia_tap >> 1) - 1 + up_py; ia_dx = (ia_tap & 1) - 1 + up_px;
       } else {
         ++ia_tap; ++ia_dx;
         if (ia_dx > 1) { ia_dx = -1; ++ia_dy; }
@@ -1655,6 +1688,8 @@ static bool g_splitk = true;
 static int g_force_nsplit = 0;   // development: > 0 forces that split-K factor wherever a workspace is attached
 void set_gemm_force_nsplit(int v) { g_force_nsplit = v; }
 static bool g_use_dma = true;
+bool g_up4 = true;          // up-sampling 3x3 convolutions as four 2x2 phase convolutions where the caller supplies Bw4 (plan switch 21)
+void set_gemm_up4(bool on) { g_up4 = on; }
 bool g_conv_halo = false;    // 3x3 convolutions on whole-image-row tiles: input halo resident in LDS (conv_halo_kernel)
 void set_gemm_conv_halo(bool on) { g_conv_halo = on; }
 int g_dbg = 0;   // timing-only ablations (results are wrong when non-zero): 1 no epilogue, 2 no DMA in loop, 4 no reads/MFMA
@@ -1888,19 +1923,21 @@ template <typename TC, int MODE, int BM, int BN, int WM, int WN, int NST, int NS
 static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
   constexpr int smem = NST * BM * 128 + NSTB * BN * 128;
   constexpr int threads = WM * WN * 64;
-  if constexpr (MF16 && !REGE) {          // the register epilogue wherever it covers the launch
+  if constexpr (MF16 && !REGE && MODE != 3) {          // the register epilogue wherever it covers the launch
     if (reg_epilogue_ok(p, dma_plan(p).nsplit, g_dbg)) return launch_dma_geom<TC, MODE, BM, BN, WM, WN, NST, NSTB, true, true>(p, stream);
   }
   auto kern = gemm_dma_kernel<TC, BM, BN, WM, WN, MODE, NST, NSTB, MF16, REGE>;
   T2P_TRY(ensure_dynamic_lds((const void*)kern, smem));
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-  const int nsplit = dma_plan(p).nsplit;
+  const int Mq = MODE == 3 ? p.M / 4 : p.M;               // MODE 3: one output phase per launch
+  const int tiles_m = (Mq + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int nsplit = MODE == 3 ? 1 : dma_plan(p).nsplit;
   dim3 grid(tiles_m * tiles_n, p.nz0 * p.nz1, nsplit);
   ProfRec rec;
   if (g_prof_on) {
     T2P_HIP_CHECK(hipEventCreate(&rec.a));
     T2P_HIP_CHECK(hipEventCreate(&rec.b));
-    rec.flops = 2.0 * p.M * p.N * (double)p.taps * (p.C0 + p.C1) * p.nz0 * p.nz1;
+    rec.flops = MODE == 3 ? 2.0 * Mq * p.N * 4.0 * (p.C0 + p.C1)          // the multiplications this launch executes
+                          : 2.0 * p.M * p.N * (double)p.taps * (p.C0 + p.C1) * p.nz0 * p.nz1;
     rec.kind = p.taps == 9 ? 0 : 1;
     static const std::string kname = std::string("gemm_dma_kernel<") + (dtype_of<TC>::value == DT_F16 ? "f16_t" : "bf16_t") + ", " +
                                      std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) +
@@ -1968,9 +2005,34 @@ static int launch_conv_halo(const GemmParams& p, hipStream_t stream) {
   return T2P_OK;
 }
 
+// a 3x3 convolution on a 2x up-sampled map as four 2x2 convolutions on the source map (kernel MODE 3): the caller supplied
+// the phase weights (GemmParams::Bw4), the 16x16x32 geometries with the register epilogue run it
+static bool up4_eligible(const GemmParams& p, const DmaPlan& plan) {
+  if (!g_up4 || !p.Bw4 || p.taps != 9 || !p.a_up || plan.nsplit != 1 || (plan.geom != 1 && plan.geom != 3) || g_dma_ring != 2) return false;
+  if (p.nz0 * p.nz1 != 1 || p.R || p.bias_m || p.geglu || p.A1) return false;
+  const int Ws = p.W / 2, HWs = (p.H / 2) * (p.W / 2);
+  if (p.H % 2 || p.W % 2 || Ws % 16 != 0 || HWs % 64 != 0 || p.M % (p.H * p.W) != 0) return false;
+  if (p.bias_bn && p.rows_per_batch != p.H * p.W) return false;
+  if ((long)p.N * p.ldb4 * 2 * 4 >= (1L << 31) - 64) return false;
+  return reg_epilogue_ok(p, 1, g_dbg);
+}
+
 template <typename TC, int MODE>
 int launch_dma_mode(const GemmParams& p, hipStream_t stream) {
   const DmaPlan plan = dma_plan(p);
+  if constexpr (MODE == 2) {
+    if (up4_eligible(p, plan)) {
+      GemmParams q = p;
+      q.ldb = p.ldb4;
+      for (int ph = 0; ph < 4; ++ph) {
+        q.up_phase = ph + 1;
+        q.Bw = (const TC*)p.Bw4 + (long)ph * p.N * p.ldb4;
+        if (plan.geom == 1) T2P_TRY((launch_dma_geom<TC, 3, 256, 256, 2, 4, 2, 2, true, true>(q, stream)));
+        else T2P_TRY((launch_dma_geom<TC, 3, 512, 128, 4, 2, 2, 2, true, true>(q, stream)));
+      }
+      return T2P_OK;
+    }
+  }
   if constexpr (MODE == 1) {
     if (conv_halo_eligible(p, plan)) {
       if (plan.geom == 1) return launch_conv_halo<TC, 256, 256, 2, 4, 2>(p, stream);

@@ -103,6 +103,12 @@ struct GemmParams {
   int a_up = 0;              // source map is (H/2, W/2)
   const void* Bw = nullptr;  // [N][ldb] compute dtype, K index = tap * (C0 + C1) + c
   long ldb = 0;
+  // optional, taps == 9 with a_up: phase weights of the same convolution, [4 phases (py, px)][N][ldb4], K index =
+  // (ty * 2 + tx) * C0 + c -- the 3x3 taps that read the same source pixel summed (Engine::upload_up4); lets launch_gemm run
+  // the layer as four 2x2 convolutions on the source map (4 / 9 of the multiplications)
+  const void* Bw4 = nullptr;
+  long ldb4 = 0;
+  int up_phase = 0;          // set by launch_gemm: 1 + phase of a MODE 3 launch
   int M = 0, N = 0;
   // batching over blockIdx.z = z0 * nz1 + z1
   int nz0 = 1, nz1 = 1;
@@ -143,6 +149,7 @@ void set_gemm_force_nsplit(int v);
 void set_gemm_midsplit(bool on);
 void set_gemm_thin_conv(bool on);
 void set_gemm_conv_halo(bool on);
+void set_gemm_up4(bool on);
 extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible
 extern bool g_lowp_h1;         // engine: block-internal conv0 output stored in the compute dtype
 extern bool g_lowp_residual;   // engine: residual stream between blocks in the compute dtype (f16 mode)
