@@ -398,6 +398,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 17) { g_gn_apply16 = value != 0; return T2P_OK; }
   if (key == 20) { g_layernorm16 = value != 0; return T2P_OK; }
   if (key == 21) { set_gemm_up4(value != 0); return T2P_OK; }
+  if (key == 22) { set_gemm_deep_ring(value != 0); return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) {
 #ifndef T2P_ABLATION

@@ -147,7 +147,8 @@ struct DmaPlan { int geom, nsplit; };
 extern bool g_prof_on;
 extern std::vector<ProfRec> g_prof;
 extern int g_dma_ring, g_dbg;
-extern bool g_conv_halo, g_up4;
+extern bool g_conv_halo, g_up4, g_deep_ring;
+int num_cus();
 DmaPlan dma_plan(const GemmParams& p);
 int launch_splitk_reduce(const GemmParams& p, int nsplit, hipStream_t stream);
 template <typename TC, int MODE> int launch_dma_mode(const GemmParams& p, hipStream_t stream);
@@ -1234,13 +1235,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   // the top of iteration kt everything up to and including A(kt) and B(kt) has landed when at most
   // the loads issued after them are outstanding.
   constexpr int AA = NST - 1, AB = NSTB - 1;            // lead (K-tiles) of the A and B streams
+  static_assert(AA <= 3 && (NSTB == NST || AA == 2), "ring depths: 2, 3 or 4 symmetric stages, or 3 + 2");
   issue(0, 2);
   if (AA > 1 && nk > 1) issue(1, AB > 1 ? 2 : 0);
+  if (AA > 2 && nk > 2) issue(2, 2);
   for (int kt = 0; kt < nk; ++kt) {
-    // outstanding after A(kt), B(kt) in issue order: symmetric ring: the (AA - 1) younger tiles;
-    // asymmetric (AB == AA - 1): only A(kt + 1 .. kt + AA - 1)
-    if (kt + 1 < nk && AA > 1) {
-      if (NSTB == NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AA - 1) * (A_INSTR + B_INSTR)) : "memory");
+    // outstanding after A(kt), B(kt) in issue order: symmetric ring: the min(AA - 1, nk - 1 - kt) younger tiles (the tail of
+    // the loop has fewer); asymmetric (AB == AA - 1): only A(kt + 1 .. kt + AA - 1)
+    const int young = nk - 1 - kt;
+    if (AA > 2 && young >= 2) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (A_INSTR + B_INSTR)) : "memory");
+    } else if (AA > 1 && young >= 1) {
+      if (NSTB == NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR + B_INSTR) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AA - 1) * A_INSTR) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1688,6 +1694,18 @@ static bool g_splitk = true;
 static int g_force_nsplit = 0;   // development: > 0 forces that split-K factor wherever a workspace is attached
 void set_gemm_force_nsplit(int v) { g_force_nsplit = v; }
 static bool g_use_dma = true;
+bool g_deep_ring = true;    // small launches of the 128 x 128 geometry on a 4-stage ring (plan switch 22)
+void set_gemm_deep_ring(bool on) { g_deep_ring = on; }
+int num_cus() {
+  static int n[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (!n[dev]) {
+    hipDeviceProp_t prop;
+    n[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  return n[dev];
+}
 bool g_up4 = true;          // up-sampling 3x3 convolutions as four 2x2 phase convolutions where the caller supplies Bw4 (plan switch 21)
 void set_gemm_up4(bool on) { g_up4 = on; }
 bool g_conv_halo = false;    // 3x3 convolutions on whole-image-row tiles: input halo resident in LDS (conv_halo_kernel)
@@ -1862,6 +1880,10 @@ DmaPlan dma_plan(const GemmParams& p) {
     nsplit = std::min(std::min(nk / 4, (384 + tiles - 1) / tiles), 32);
   }
   while (nsplit > 1 && !fits(nsplit)) --nsplit;
+  // 128 x 128 tiles on at most one workgroup per CU: such a launch is bound by the latency of its K-steps (0.47 us each with
+  // the 2-stage ring: every step waits for the DMA issued one step earlier), so it takes the 4-stage ring (geometry 4: the
+  // same tile with three K-tiles in flight, 128 KiB of LDS)
+  if (geom == 2 && g_deep_ring && (long)tiles * nsplit * z <= num_cus()) geom = 4;
   return {geom, nsplit};
 }
 static bool dma_uses_splitk(const GemmParams& p) { return dma_plan(p).nsplit > 1; }
@@ -2045,6 +2067,7 @@ int launch_dma_mode(const GemmParams& p, hipStream_t stream) {
       if (g_dma_ring == 1) return launch_dma_geom<TC, MODE, 256, 256, 2, 4, 2>(p, stream);
       return launch_dma_geom<TC, MODE, 256, 256, 2, 4, 3, 2>(p, stream);   // 3 A stages + 2 B stages = 160 KiB
     case 2: return launch_dma_geom<TC, MODE, 128, 128, 2, 2, 2>(p, stream);
+    case 4: return launch_dma_geom<TC, MODE, 128, 128, 2, 2, 4>(p, stream);
     case 3:
       if (g_dma_ring == 2) return launch_dma_geom<TC, MODE, 512, 128, 4, 2, 2, 2, true>(p, stream);
       return launch_dma_geom<TC, MODE, 512, 128, 4, 2, 2>(p, stream);

@@ -150,6 +150,7 @@ void set_gemm_midsplit(bool on);
 void set_gemm_thin_conv(bool on);
 void set_gemm_conv_halo(bool on);
 void set_gemm_up4(bool on);
+void set_gemm_deep_ring(bool on);
 extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible
 extern bool g_lowp_h1;         // engine: block-internal conv0 output stored in the compute dtype
 extern bool g_lowp_residual;   // engine: residual stream between blocks in the compute dtype (f16 mode)
