@@ -419,7 +419,7 @@ def test_conv_midsize_splitk_plan(lib):
             assert not torch.equal(outs[0], outs[1])     # the two plans sum in different orders
     finally:
         lib.t2p_debug_set(10, 0)
-        lib.t2p_debug_set(12, 1)
+        lib.t2p_debug_set(12, 0)
 
 
 @pytest.mark.parametrize("dt", [1, 2])
