@@ -148,6 +148,13 @@ int t2p_op_gemm_r16(int dtype, const void* A, int a_f32, const void* Bw, void* C
 /* x: NHWC in the given layout; w: [Cout][3][3][Cin] compute dtype; out fp32 NHWC */
 int t2p_op_conv3x3(int dtype, const void* x, int a_f32, const void* w, const float* bias, float* out, int batch,
                    int H, int W, int Cin, int Cout, int upsample, void* stream);
+/* second convolution of a residual block with its 1x1 shortcut in the same K loop (layers.py:322-327, h + Conv_2(x)):
+ * out = alpha * (conv3x3(a) + [x0 | x1] Wx^T + bias); a, x0, x1: NHWC compute dtype (x1 may be NULL with CX1 = 0: the
+ * second source of a concatenated block input); w: [Cout][9 * C + CX0 + CX1], the 3x3 taps first; out fp32 or compute
+ * dtype.  16-bit modes on the LDS-DMA kernels only (C, CX0, CX1 multiples of 64): anything else is refused */
+int t2p_op_conv3x3_shortcut(int dtype, const void* a, const void* w, const float* bias, const void* x0, int CX0,
+                            const void* x1, int CX1, float alpha, void* out, int c_f32, int batch, int H, int W, int C,
+                            int Cout, void* stream);
 int t2p_op_groupnorm(const float* x0, const float* x1, int C0, int C1, int batch, int H, int W, int groups,
                      const float* gamma, const float* beta, float eps, int silu, int down, void* out, int dtype,
                      void* stream);

@@ -232,3 +232,31 @@ def test_up_phase_convolution_matches_gather_form():
     for i, s in enumerate((3, chains - 2)):
         for sw in (0, 1):
             assert rel_l2(outs[sw][s], g["score"][i]) < F16_SCORE_TOL
+
+
+@pytest.mark.parametrize("stem", ["test_config", "cond_length"])
+def test_shortcut_in_the_convolution_matches_separate_shortcut(stem):
+    """Blocks with a 1x1 shortcut at their own resolution run it as an extra K segment of their second convolution (plan
+    switch 23) instead of a GEMM of its own whose fp32 result the convolution then re-reads: both forms against the
+    reference's scores at full size (the 16x16 level of test_config takes the split-K plan, whose splits cross the segment)."""
+    from text2protein_amd import _lib, synth
+    cfg, B0, T, chains = _cfg(stem)
+    g = load_golden("full_" + stem)
+    sd = synth.synth_state_dict(cfg, 0)
+    x, labels, ctx = (t.cuda() for t in full_inputs(cfg, B0, T))
+    lib = _lib.load()
+    m16 = _model(cfg, sd, "f16")
+    outs = {}
+    try:
+        for sw in (0, 1):
+            _lib.check(lib.t2p_debug_set(23, sw))
+            outs[sw] = m16(x, labels, ctx).cpu()
+    finally:
+        lib.t2p_debug_set(23, 1)
+    assert not torch.equal(outs[0], outs[1]), "the fused form did not run"
+    d = rel_l2(outs[1], outs[0])
+    e0, e1 = rel_l2(outs[0], g["score"]), rel_l2(outs[1], g["score"])
+    print(f"{stem}: shortcut in the convolution vs separate: rel-L2 = {d:.3e}; vs reference: separate {e0:.3e}, fused {e1:.3e}")
+    _record(f"shortcut_fused_{stem}", {"fused_vs_separate": d, "separate_vs_reference": e0, "fused_vs_reference": e1})
+    # two f16 evaluations with differently rounded intermediates are as far from each other as each is from the reference
+    assert d < F16_SCORE_TOL and e0 < F16_SCORE_TOL and e1 < F16_SCORE_TOL and e1 < 1.05 * e0

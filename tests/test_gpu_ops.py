@@ -447,3 +447,41 @@ def test_gemm_16bit_residual(lib, dt, M, N, K, ws):
             assert rel_l2(out.float().cpu(), ref) < tol, (dt, M, N, K, c_f32)
     finally:
         lib.t2p_debug_set(10, 0)
+
+
+@pytest.mark.parametrize("geom", [0, 1, 2, 3, 4])
+def test_conv3x3_with_shortcut_segment(lib, geom):
+    """The second convolution of a residual block with the block's 1x1 shortcut as an extra K segment of the same launch
+    (centre tap of x0 | x1; layers.py:322-327: h + Conv_2(x), then / sqrt 2): every LDS-DMA geometry, one and two shortcut
+    sources, 16-bit and fp32 output, with and without the split-K plan (whose splits may start inside the segment)."""
+    try:
+        check(lib, lib.t2p_debug_set(2, geom))
+        g = torch.Generator().manual_seed(900 + geom)
+        for dt in (1, 2):
+            td = TDT[dt]
+            for (B, H, W, C, CX0, CX1, Cout, ws) in [(2, 24, 20, 128, 64, 0, 256, 0), (1, 32, 32, 64, 128, 64, 128, 0),
+                                                    (3, 16, 16, 256, 256, 128, 256, 64), (2, 8, 8, 128, 192, 64, 128, 64)]:
+                check(lib, lib.t2p_debug_set(10, ws))
+                a = torch.randn(B, C, H, W, generator=g).to(td)
+                x = torch.randn(B, CX0 + CX1, H, W, generator=g).to(td)
+                w1 = (torch.randn(Cout, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(td)
+                w2 = (torch.randn(Cout, CX0 + CX1, 1, 1, generator=g) / (CX0 + CX1) ** 0.5).to(td)
+                b = torch.randn(Cout, generator=g)
+                ref = (F.conv2d(a.double(), w1.double(), b.double(), padding=1) + F.conv2d(x.double(), w2.double())).permute(0, 2, 3, 1) * 0.5 ** 0.5
+                wcat = torch.cat([w1.permute(0, 2, 3, 1).reshape(Cout, 9 * C), w2.reshape(Cout, CX0 + CX1)], 1).contiguous()
+                xn = x.permute(0, 2, 3, 1)
+                x0 = dev(xn[..., :CX0])
+                x1 = dev(xn[..., CX0:]) if CX1 else None
+                for c_f32 in (1, 0):
+                    out = torch.full((B, H, W, Cout), float("nan"), device="cuda", dtype=torch.float32 if c_f32 else td)
+                    check(lib, lib.t2p_op_conv3x3_shortcut(dt, P(dev(a.permute(0, 2, 3, 1))), P(dev(wcat)), P(dev(b)), P(x0), CX0,
+                                                           P(x1) if CX1 else None, CX1, 0.5 ** 0.5, P(out), c_f32, B, H, W, C, Cout, None))
+                    torch.cuda.synchronize()
+                    tol = 3e-6 if c_f32 else (6e-4 if dt == 2 else 5e-3)
+                    assert rel_l2(out.float().cpu(), ref) < tol, (geom, dt, B, H, W, C, CX0, CX1, Cout, ws, c_f32)
+    finally:
+        lib.t2p_debug_set(2, 0)
+        lib.t2p_debug_set(10, 0)
+    # shapes that are not on the LDS-DMA convolution are refused, not silently computed without the segment
+    z = torch.zeros(1, 8, 8, 32, device="cuda", dtype=torch.float16)
+    assert lib.t2p_op_conv3x3_shortcut(2, P(z), P(z), None, P(z), 32, None, 0, 1.0, P(z), 0, 1, 8, 8, 32, 32, None) != 0

@@ -62,6 +62,7 @@ SIGNATURES = {
     "t2p_sampler_step_graph": (_i, [_vp, _vp, _vp, _vp]),
     "t2p_sampler_run": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "t2p_op_gemm": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _vp, _f, _vp]),
+    "t2p_op_conv3x3_shortcut": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2p_op_gemm_r16": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _vp, _f, _vp]),
     "t2p_op_conv3x3": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2p_op_groupnorm": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp]),
@@ -104,7 +105,9 @@ def load_path(path):
         raise T2PError("load_path() must come before any other use of the library")
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)
+        if fn is None:          # an older revision: entry points added since are simply not there
+            continue
         fn.restype = res
         fn.argtypes = args
     _lib = lib

@@ -181,7 +181,18 @@ int t2p_op_gemm(int dtype, const void* A, int a_f32, const void* Bw, void* C, in
 }
 
 static void* g_op_ws = nullptr;
-static size_t g_op_ws_bytes = 0;
+static size_t g_op_ws_bytes = 0, g_op_ws_alloc = 0;
+// development switch (t2p_debug_set key 10): a split-K workspace for the op entries, so that they can take that plan
+static int attach_op_ws(GemmParams& p) {
+  if (!g_op_ws_bytes) return T2P_OK;
+  if (g_op_ws_alloc < g_op_ws_bytes) {
+    if (g_op_ws) { T2P_HIP_CHECK(hipDeviceSynchronize()); T2P_HIP_CHECK(hipFree(g_op_ws)); g_op_ws = nullptr; g_op_ws_alloc = 0; }
+    T2P_HIP_CHECK(hipMalloc(&g_op_ws, g_op_ws_bytes));
+    g_op_ws_alloc = g_op_ws_bytes;
+  }
+  p.ws = g_op_ws; p.ws_bytes = g_op_ws_bytes;
+  return T2P_OK;
+}
 
 int t2p_op_gemm_r16(int dtype, const void* A, int a_f32, const void* Bw, void* C, int c_f32, int M, int N, int K, int64_t lda,
                     int64_t ldb, int64_t ldc, const float* bias_n, const void* residual16, float alpha, void* stream) {
@@ -189,10 +200,7 @@ int t2p_op_gemm_r16(int dtype, const void* A, int a_f32, const void* Bw, void* C
   GemmParams p;
   p.dtype = dtype; p.A0 = A; p.a_f32 = a_f32; p.C0 = K; p.lda0 = lda; p.Bw = Bw; p.ldb = ldb; p.M = M; p.N = N;
   p.bias_n = bias_n; p.R = (const float*)residual16; p.r_lowp = 1; p.ldr = ldc; p.alpha = alpha; p.C = C; p.c_f32 = c_f32; p.ldc = ldc;
-  if (g_op_ws_bytes) {   // development switch (t2p_debug_set key 10): lets the op entry take the split-K path
-    if (!g_op_ws) T2P_HIP_CHECK(hipMalloc(&g_op_ws, g_op_ws_bytes));
-    p.ws = g_op_ws; p.ws_bytes = g_op_ws_bytes;
-  }
+  T2P_TRY(attach_op_ws(p));
   return launch_gemm(p, (hipStream_t)stream);
   API_END
 }
@@ -204,10 +212,21 @@ int t2p_op_conv3x3(int dtype, const void* x, int a_f32, const void* w, const flo
   p.dtype = dtype; p.A0 = x; p.a_f32 = a_f32; p.C0 = Cin; p.lda0 = Cin; p.taps = 9; p.H = H; p.W = W; p.a_up = upsample;
   p.Bw = w; p.ldb = 9L * Cin; p.M = batch * H * W; p.N = Cout; p.bias_n = bias; p.rows_per_batch = H * W;
   p.C = out; p.c_f32 = 1; p.ldc = Cout;
-  if (g_op_ws_bytes) {   // development switch (t2p_debug_set key 10): lets the op entry take the split-K path
-    if (!g_op_ws) T2P_HIP_CHECK(hipMalloc(&g_op_ws, g_op_ws_bytes));
-    p.ws = g_op_ws; p.ws_bytes = g_op_ws_bytes;
-  }
+  T2P_TRY(attach_op_ws(p));
+  return launch_gemm(p, (hipStream_t)stream);
+  API_END
+}
+
+int t2p_op_conv3x3_shortcut(int dtype, const void* a, const void* w, const float* bias, const void* x0, int CX0, const void* x1,
+                            int CX1, float alpha, void* out, int c_f32, int batch, int H, int W, int C, int Cout, void* stream) {
+  API_BEGIN
+  GemmParams p;
+  p.dtype = dtype; p.A0 = a; p.a_f32 = 0; p.C0 = C; p.lda0 = C; p.taps = 9; p.H = H; p.W = W;
+  p.Bw = w; p.ldb = 9L * C + CX0 + CX1; p.M = batch * H * W; p.N = Cout; p.bias_n = bias; p.rows_per_batch = H * W;
+  p.alpha = alpha; p.C = out; p.c_f32 = c_f32; p.ldc = Cout;
+  T2P_TRY(attach_op_ws(p));
+  T2P_REQUIRE(gemm_can_fuse_shortcut(p), "this convolution does not take the shortcut segment (LDS-DMA 3x3 convolutions only)");
+  p.X0 = x0; p.CX0 = CX0; p.ldx0 = CX0; p.X1 = x1; p.CX1 = CX1; p.ldx1 = CX1;
   return launch_gemm(p, (hipStream_t)stream);
   API_END
 }
@@ -399,6 +418,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 20) { g_layernorm16 = value != 0; return T2P_OK; }
   if (key == 21) { set_gemm_up4(value != 0); return T2P_OK; }
   if (key == 22) { set_gemm_deep_ring(value != 0); return T2P_OK; }
+  if (key == 23) { set_gemm_fuse_shortcut(value != 0); return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) {
 #ifndef T2P_ABLATION

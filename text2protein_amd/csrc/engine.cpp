@@ -442,6 +442,25 @@ int Engine::finalize() {
       }
       T2P_TRY(upload_linear(p + ".Conv_1.weight", p + ".Conv_1.bias", co, 9 * co, &l.conv1, true));
       if (l.has_conv2) T2P_TRY(upload_linear(p + ".Conv_2.weight", p + ".Conv_2.bias", co, ci, &l.conv2));
+      if (l.has_conv2 && !l.up && !l.down && cfg_.compute_dtype != DT_F32 && ci % 64 == 0 && co % 64 == 0) {
+        // h + shortcut(x) = [conv1 | conv2] applied to [3x3 window of a1 | x] (layers.py:322-327): one K loop, one fp32 sum
+        const HostTensor* w1 = host(p + ".Conv_1.weight", {co, co, 3, 3});
+        const HostTensor* w2 = host(p + ".Conv_2.weight", {co, ci, 1, 1});
+        const HostTensor* b1 = host(p + ".Conv_1.bias", {co});
+        const HostTensor* b2 = host(p + ".Conv_2.bias", {co});
+        if (!w1 || !w2 || !b1 || !b2) return T2P_ERR_STATE;
+        const std::vector<float> m1 = to_nk(*w1, true, false, 0);
+        const size_t K1 = (size_t)9 * co, Kx = K1 + ci;
+        std::vector<float> m((size_t)co * Kx), bb(co);
+        for (int n = 0; n < co; ++n) {
+          std::copy(m1.begin() + n * K1, m1.begin() + (n + 1) * K1, m.begin() + n * Kx);
+          std::copy(w2->data.begin() + (size_t)n * ci, w2->data.begin() + (size_t)(n + 1) * ci, m.begin() + n * Kx + K1);
+          bb[n] = b1->data[n] + b2->data[n];
+        }
+        T2P_TRY(upload_matrix(pool_, m, cfg_.compute_dtype, &l.conv1x.w));
+        T2P_TRY(upload_f32(bb, &l.conv1x.b));
+        l.conv1x.N = co; l.conv1x.K = (int)Kx;
+      }
       const HostTensor* w = host(p + ".Dense_0.weight", {co, td});
       const HostTensor* b = host(p + ".Dense_0.bias", {co});
       if (!w || !b) return T2P_ERR_STATE;
@@ -665,12 +684,32 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
   void* a1 = nullptr;
   T2P_TRY(group_norm(h1a, nullptr, L.gn1, 1e-6f, 1, 0, B, &a1, s));
   free_act(h1a);
+  // second convolution; set up here because the shortcut may ride in its K loop
+  GemmParams pc;
+  pc.dtype = dt; pc.A0 = a1; pc.a_f32 = dt == DT_F32; pc.C0 = Cout; pc.lda0 = Cout;
+  pc.taps = 9; pc.H = Ho; pc.W = Wo;
+  pc.Bw = L.conv1.w; pc.ldb = L.conv1.K; pc.M = (int)rows_out; pc.N = Cout;
+  pc.bias_n = L.conv1.b; pc.rows_per_batch = Ho * Wo;
+  pc.alpha = cfg_.skip_rescale ? 0.70710678118654752440f : 1.f;
+  bool fused_shortcut = false;
+  if (L.conv1x.w && (x.lowp || xraw) && x.C % 64 == 0 && (!skip || skip->C % 64 == 0) && gemm_can_fuse_shortcut(pc)) {
+    fused_shortcut = true;
+    pc.Bw = L.conv1x.w; pc.ldb = L.conv1x.K; pc.bias_n = L.conv1x.b;
+    if (xraw) {
+      pc.X0 = xraw; pc.CX0 = Cin; pc.ldx0 = Cin;
+    } else {
+      pc.X0 = x.p; pc.CX0 = x.C; pc.ldx0 = x.C;
+      if (skip) { pc.X1 = skip->p; pc.CX1 = skip->C; pc.ldx1 = skip->C; }
+    }
+  }
   // shortcut branch
   const float* r = x.p;
   float* rbuf = nullptr;
   bool rbuf_lowp = false;
   int r_up = 0;
-  if (L.has_conv2) {
+  if (fused_shortcut) {
+    r = nullptr;
+  } else if (L.has_conv2) {
     GemmParams p;
     p.dtype = dt; p.a_f32 = dt == DT_F32;
     void* pooled = nullptr;
@@ -707,20 +746,13 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
   const bool olp = res_lowp();           // block output (the residual stream) in the compute dtype
   POOL_GET(o, float*, (size_t)rows_out * Cout * (olp ? dtype_size(dt) : 4));
   float* o_stats = nullptr;
-  {
-    GemmParams p;
-    p.dtype = dt; p.A0 = a1; p.a_f32 = dt == DT_F32; p.C0 = Cout; p.lda0 = Cout;
-    p.taps = 9; p.H = Ho; p.W = Wo;
-    p.Bw = L.conv1.w; p.ldb = L.conv1.K; p.M = (int)rows_out; p.N = Cout;
-    p.bias_n = L.conv1.b; p.rows_per_batch = Ho * Wo;
-    p.R = r; p.ldr = Cout; p.r_up = r_up;
-    p.r_lowp = (r == x.p ? x.lowp : rbuf_lowp) ? 1 : 0;   // identity shortcut: the block input itself
-    p.alpha = cfg_.skip_rescale ? 0.70710678118654752440f : 1.f;
-    p.C = o; p.c_f32 = olp ? 0 : 1; p.ldc = Cout;
-    T2P_TRY(gemm_stats(p, &o_stats, s));
-  }
+  pc.R = r; pc.ldr = Cout; pc.r_up = r_up;
+  pc.r_lowp = (r == x.p ? x.lowp : rbuf_lowp) ? 1 : 0;   // identity shortcut: the block input itself
+  pc.C = o; pc.c_f32 = olp ? 0 : 1; pc.ldc = Cout;
+  T2P_TRY(gemm_stats(pc, &o_stats, s));
   pool_.put(a1);
   pool_.put(rbuf);
+  if (fused_shortcut) pool_.put(xraw);
   *out = Act{o, Cout, Ho, Wo, o_stats, olp};
   return T2P_OK;
 }

@@ -56,6 +56,9 @@ struct Layer {
   DevNorm gn0, gn1;
   DevLinear conv0, conv1, conv2;
   void* conv0_up4 = nullptr;   // up blocks, 16-bit modes: conv0 as four 2x2 phase convolutions, [4][Cout][4 * Cin] (GemmParams::Bw4)
+  // blocks with a 1x1 shortcut at the block's own resolution, 16-bit modes: conv1 and the shortcut as one K loop,
+  // weights [Cout][9 * Cout + Cin] and bias b1 + b2 (GemmParams::X0)
+  DevLinear conv1x;
   bool has_conv2 = false;
   int temb_off = 0;
   // attn (AttnBlockpp): NIN_0|NIN_1 stacked, NIN_2, NIN_3

@@ -1048,7 +1048,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
 
   const int Ctot = p.C0 + p.C1;
   const int nch = (Ctot + BK - 1) / BK;
-  const int nk_all = nch * TAPS;
+  // MODE 1 only: an extra K segment read at the centre tap from X0 | X1 (the 1x1 shortcut of a residual block folded into its
+  // second convolution): nchx more 64-channel K-tiles after the nch * 9 main ones
+  const int nchx = MODE == 1 ? (p.CX0 + p.CX1) / BK : 0;
+  const int nk_all = nch * TAPS + nchx;
   // split-K: blockIdx.z owns K-tiles [kt_lo, kt_hi) and writes a raw fp32 partial tile
   const int nsplit = gridDim.z, ks = blockIdx.z;
   const int kt_lo = (int)((long)nk_all * ks / nsplit), kt_hi = (int)((long)nk_all * (ks + 1) / nsplit);
@@ -1070,8 +1073,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   const TC* Bp = (const TC*)p.Bw + (long)z0 * p.sB_z0 + (long)z1 * p.sB_z1;
   const int a0_bytes = (int)(((a_rows - 1) * p.lda0 + p.C0) * 2);
   const int a1_bytes = p.A1 ? (int)(((a_rows - 1) * p.lda1 + p.C1) * 2) : 0;
-  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bp, (int)((((long)p.N - 1) * p.ldb + (long)TAPS * Ctot) * 2));
+  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bp, (int)((((long)p.N - 1) * p.ldb + (long)TAPS * Ctot + nchx * BK) * 2));
   const unsigned lda0_2 = (unsigned)(p.lda0 * 2), lda1_2 = (unsigned)(p.lda1 * 2);
+  const unsigned ldx0_2 = (unsigned)(p.ldx0 * 2), ldx1_2 = (unsigned)(p.ldx1 * 2);
+  // (fields copied out: `c ? p.a : p.b` is an lvalue conditional -- an address select into the by-value argument struct, which
+  // then lands in scratch memory)
+  const void* const X0p = p.X0; const void* const X1p = p.X1; const void* const A1p = p.A1;
+  const int pC0 = p.C0, pCX0 = p.CX0;
+  const int x0_bytes = nchx ? (int)((((long)p.M - 1) * p.ldx0 + p.CX0) * 2) : 0;
+  const int x1_bytes = (nchx && p.X1) ? (int)((((long)p.M - 1) * p.ldx1 + p.CX1) * 2) : 0;
 
   // per-lane DMA geometry: instruction j of this wave covers tile rows (wave * INSTR + j) * 8 + (lane >> 3).
   // K order is chunk-major (all 9 taps of one 64-channel slice back to back: the 3x3 window
@@ -1079,13 +1089,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   // (NHWC rows are pixel-major), so per K-tile the lane adds one wave-uniform byte delta to a
   // precomputed offset; bit t of a_vm says whether tap t lands inside the map.
   const int prow = lane >> 3, ppos = lane & 7;
-  unsigned a_off0[A_INSTR], a_off1[A_INSTR], a_vm[A_INSTR];
+  // a lane keeps the row m of each of its instructions (24-bit: offset = m * row stride + chunk through one v_mad_u32_u24,
+  // whatever the source), the swizzled chunk offset (it depends on the parity of j only) and the tap-validity bits
+  static_assert(A_INSTR % 2 == 0, "the chunk swizzle of instruction j depends on j & 1 only when A_INSTR is even");
+  unsigned a_m[A_INSTR], a_vm[A_INSTR], a_chk[2];
   int a_y[A_INSTR], a_x[A_INSTR], a_bb[A_INSTR];       // MODE 2 only
+  a_chk[0] = (unsigned)((ppos ^ ((prow >> 1) & 7)) * 16);
+  a_chk[1] = (unsigned)((ppos ^ ((4 + (prow >> 1)) & 7)) * 16);
 #pragma unroll
   for (int j = 0; j < A_INSTR; ++j) {
     const int r = (wave * A_INSTR + j) * 8 + prow;
     const int m = m0 + r;
-    const unsigned chunk = (unsigned)((ppos ^ ((r >> 1) & 7)) * 16);
     unsigned vm = 0;
     int y = 0, x = 0, b = 0;
     if (MODE != 0) {
@@ -1113,9 +1127,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
     }
     a_vm[j] = vm;
     a_y[j] = y; a_x[j] = x; a_bb[j] = b * Hs * Ws;
-    a_off0[j] = (unsigned)m * lda0_2 + chunk;        // MODE 2 recomputes the row per tap
-    a_off1[j] = (unsigned)m * lda1_2 + chunk;
-    if (MODE == 2) { a_off0[j] = chunk; a_off1[j] = chunk; }
+    a_m[j] = (unsigned)m;                            // MODE 2 recomputes the row per tap
   }
   unsigned b_off[B_INSTR];
 #pragma unroll
@@ -1125,64 +1137,128 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
     b_off[j] = n < p.N ? (unsigned)((long)n * p.ldb * 2) + (unsigned)((ppos ^ ((r >> 1) & 7)) * 16) : DMA_OOB;
   }
 
-  // Issue-stream state (wave-uniform).  The A and the B stream are each issued strictly in K order, every K-tile once, so
-  // the (chunk, tap, ring stage) of a stream's next K-tile are carried along instead of being divided out of the K index at
-  // every issue: the scalar prelude of an issue is what the two waves of a SIMD cannot hide from each other.
-  int ia_chunk = kt_lo / TAPS, ia_tap = kt_lo - (kt_lo / TAPS) * TAPS, ia_st = 0;
-  int ia_dy = MODE == 3 ? (ia_tap >> 1) - 1 + up_py : (MODE != 0 ? ia_tap / 3 - 1 : 0);
-  int ia_dx = MODE == 3 ? (ia_tap & 1) - 1 + up_px : (MODE != 0 ? ia_tap - (ia_tap / 3) * 3 - 1 : 0);
-  int ib_chunk = ia_chunk, ib_tap = ia_tap, ib_st = 0;
-  auto issue = [&](int /* kl: the streams keep their own position */, int part) {   // part 0: A rows, 1: B rows, 2: both
+  // Issue-stream state (wave-uniform, SGPRs).  The A and the B stream are each issued strictly in K order, every K-tile once,
+  // so each stream carries the position of its NEXT K-tile along: (chunk, tap, ring stage) plus everything an issue needs in
+  // ready-made form -- the source's buffer descriptor and row stride (they change with the 64-channel chunk), and the
+  // wave-uniform byte offset of the tap, advanced by one row stride per tap.  The common case of an issue is then a handful of
+  // scalar additions; the recomputation at a chunk boundary sits in a block that one issue in nine enters (the empty asm
+  // statements keep the compiler from turning those blocks into select chains executed every time).  The scalar prelude of
+  // an issue is what the two waves of a SIMD cannot hide from each other: ten more scalar instructions per issue measured
+  // 3.7 % on the convolutions.
+  int ia_chunk = kt_lo / TAPS, ia_tap = kt_lo - (kt_lo / TAPS) * TAPS;
+  if (nchx && kt_lo >= nch * TAPS) { ia_chunk = nch + (kt_lo - nch * TAPS); ia_tap = 0; }     // a K-split that starts in the extra segment
+  int ib_chunk = ia_chunk, ib_tap = ia_tap;
+  unsigned ia_so = 0, ib_so = 0;                        // ring stage byte offsets
+  int ia_dx = 0;                                        // MODE 1: column of the tap (-1, 0, 1): the row of taps ends after dx = 1
+  __amdgpu_buffer_rsrc_t rA = make_rsrc(A0p, a0_bytes);
+  unsigned a_ld2 = lda0_2, a_delta = 0, a_rowstep = 0;
+  bool a_extra = false;
+  // descriptor / stride / offsets of chunk ia_chunk, tap ia_tap
+  auto a_set_chunk = [&]() __attribute__((always_inline)) {
+    const bool extra = MODE == 1 && ia_chunk >= nch;   // K-tile of the shortcut segment (centre tap of X0 | X1)
+    const int c0 = (extra ? ia_chunk - nch : ia_chunk) * BK;     // channel base of this K-tile
+    int cfirst = pC0;
+    if (extra) cfirst = pCX0;
+    const bool second = c0 >= cfirst;                  // C0 % 64 == 0
+    const int csrc = second ? c0 - cfirst : c0;
+    // (plain assignments: a nested `c ? a : b` over named variables is an address select that keeps them in memory)
+    unsigned ld2 = lda0_2;
+    const void* abase = (const void*)A0p;
+    int abytes = a0_bytes;
+    if (extra) {
+      if (second) { ld2 = ldx1_2; abase = X1p; abytes = x1_bytes; } else { ld2 = ldx0_2; abase = X0p; abytes = x0_bytes; }
+    } else if (second) {
+      ld2 = lda1_2; abase = A1p; abytes = a1_bytes;
+    }
+    rA = make_rsrc(abase, abytes);
+    a_ld2 = ld2;
+    a_extra = extra;
+    int dy = 0, dx = 0;
+    if (MODE == 1) {
+      if (extra) { ia_tap = 4; ia_dx = 1; }            // tap 4 = the centre; dx = 1: the next advance leaves the "row of taps"
+      else { dy = ia_tap / 3 - 1; dx = ia_tap - (ia_tap / 3) * 3 - 1; ia_dx = dx; }
+      a_rowstep = (unsigned)(Wq - 3) * ld2;            // from (dy, dx = 2) to (dy + 1, -1)
+    } else if (MODE == 3) {
+      dy = (ia_tap >> 1) - 1 + up_py; dx = (ia_tap & 1) - 1 + up_px;
+      a_rowstep = (unsigned)(Wq - 2) * ld2;            // from (ty, tx = 2) to (ty + 1, 0)
+    }
+    a_delta = (unsigned)((dy * Wq + dx) * (int)ld2 + csrc * 2);
+  };
+  a_set_chunk();
+  const int a_switch = p.A1 ? pC0 / BK : 0x7fffffff;    // MODE 0: the chunk at which the second source starts
+  const unsigned Ctot2 = (unsigned)(Ctot * 2);
+  unsigned b_kb = (MODE == 1 && ib_chunk >= nch) ? (unsigned)(((long)TAPS * Ctot + (ib_chunk - nch) * BK) * 2)
+                                                 : (unsigned)(((long)ib_tap * Ctot + ib_chunk * BK) * 2);
+  if (MODE == 1 && ib_chunk >= nch) ib_tap = TAPS - 1;
+  auto issue = [&](int /* kl: the streams keep their own position */, int part) __attribute__((always_inline)) {   // part 0: A rows, 1: B rows, 2: both
     if (part != 1) {
-      unsigned char* sta = smem + ia_st * ASTAGE;
-      const int c0 = ia_chunk * BK;                      // channel base of this K-tile
-      const bool second = c0 >= p.C0;                    // wave-uniform: C0 % 64 == 0
-      const int csrc = second ? c0 - p.C0 : c0;
-      const unsigned ld2 = second ? lda1_2 : lda0_2;
-      const __amdgpu_buffer_rsrc_t rA = make_rsrc(second ? (const void*)p.A1 : (const void*)A0p, second ? a1_bytes : a0_bytes);
-      const unsigned udelta = (unsigned)((ia_dy * Wq + ia_dx) * (int)ld2 + csrc * 2);   // wave-uniform
+      unsigned char* sta = smem + ia_so;
+      if constexpr (MODE == 2) {
+        const int dy = ia_tap / 3 - 1, dx = ia_tap - (ia_tap / 3) * 3 - 1;
 #pragma unroll
-      for (int j = 0; j < A_INSTR; ++j) {
-        unsigned voff;
-        if (MODE == 2) {
-          const int row = a_bb[j] + ((a_y[j] + ia_dy) >> 1) * Ws + ((a_x[j] + ia_dx) >> 1);
-          voff = (unsigned)row * ld2 + (unsigned)(csrc * 2) + a_off0[j];
-        } else {
-          voff = (second ? a_off1[j] : a_off0[j]) + udelta;
+        for (int j = 0; j < A_INSTR; ++j) {
+          const int row = a_bb[j] + ((a_y[j] + dy) >> 1) * Ws + ((a_x[j] + dx) >> 1);
+          const unsigned voff = (unsigned)row * a_ld2 + a_delta + a_chk[j & 1];     // a_delta: the channel offset only
+          const unsigned m = (dbg & 64) ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)a_vm[j], (unsigned)ia_tap, 1u);
+          unsigned char* dst = sta + (wave * A_INSTR + j) * 1024;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, T2P_LDS_PTR(dst), 16, (voff & m) | (DMA_OOB & ~m), 0, 0, 0);
         }
-        // tap validity: bit ia_tap of a_vm[j] spread over the word (v_bfe_i32), then offset-or-out-of-range in one v_bfi_b32
-        const unsigned m = (dbg & 64) ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)a_vm[j], (unsigned)ia_tap, 1u);
-        unsigned char* dst = sta + (wave * A_INSTR + j) * 1024;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, T2P_LDS_PTR(dst), 16, (voff & m) | (DMA_OOB & ~m), 0, 0, 0);
-      }
-      ia_st = ia_st + 1 == NST ? 0 : ia_st + 1;
-      if (TAPS == 1) {
-        ++ia_chunk;
-      } else if (MODE == 3) {
-        ++ia_tap;
-        if (ia_tap == TAPS) { ia_tap = 0; ++ia_chunk; }
-        ia_dy = (ia_tap >> 1) - 1 + up_py; ia_dx = (ia_tap & 1) - 1 + up_px;
       } else {
-        ++ia_tap; ++ia_dx;
-        if (ia_dx > 1) { ia_dx = -1; ++ia_dy; }
-        if (ia_tap == TAPS) { ia_tap = 0; ++ia_chunk; ia_dy = -1; ia_dx = -1; }
+        const unsigned vb0 = a_chk[0] + a_delta, vb1 = a_chk[1] + a_delta;
+#pragma unroll
+        for (int j = 0; j < A_INSTR; ++j) {
+          const unsigned voff = __umul24(a_m[j], a_ld2) + ((j & 1) ? vb1 : vb0);     // rows and strides are below 2^24 (dma_eligible)
+          // tap validity: bit ia_tap of a_vm[j] spread over the word (v_bfe_i32), then offset-or-out-of-range in one bit-select
+          const unsigned m = (dbg & 64) ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)a_vm[j], (unsigned)ia_tap, 1u);
+          unsigned char* dst = sta + (wave * A_INSTR + j) * 1024;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, T2P_LDS_PTR(dst), 16, (voff & m) | (DMA_OOB & ~m), 0, 0, 0);
+        }
+      }
+      if constexpr (NST == 2) ia_so ^= (unsigned)ASTAGE;
+      else ia_so = ia_so + ASTAGE == NST * ASTAGE ? 0u : ia_so + ASTAGE;
+      // advance to the next K-tile of the stream
+      if constexpr (MODE == 0) {
+        ++ia_chunk; a_delta += BK * 2;
+        if (ia_chunk == a_switch) { asm volatile(""); a_set_chunk(); }
+      } else if constexpr (MODE == 1) {
+        ++ia_tap; ++ia_dx; a_delta += a_ld2;
+        if (ia_dx > 1) {
+          asm volatile("");
+          ia_dx = -1; a_delta += a_rowstep;
+          if (ia_tap == TAPS || a_extra) { asm volatile(""); ia_tap = 0; ++ia_chunk; a_set_chunk(); }
+        }
+      } else if constexpr (MODE == 3) {
+        ++ia_tap; a_delta += a_ld2;
+        if (!(ia_tap & 1)) {
+          asm volatile("");
+          a_delta += a_rowstep;
+          if (ia_tap == TAPS) { asm volatile(""); ia_tap = 0; ++ia_chunk; a_set_chunk(); }
+        }
+      } else {
+        ++ia_tap;
+        if (ia_tap == TAPS) { asm volatile(""); ia_tap = 0; ++ia_chunk; a_set_chunk(); }
       }
     }
     if (part != 0) {
-      unsigned char* stb = smem + BRING + ib_st * BSTAGE;
-      const unsigned kb = (unsigned)(((long)ib_tap * Ctot + ib_chunk * BK) * 2);
+      unsigned char* stb = smem + BRING + ib_so;
 #pragma unroll
       for (int j = 0; j < B_INSTR; ++j) {
-        const unsigned voff = (dbg & 64) ? DMA_OOB : b_off[j] + kb;   // rows beyond N carry DMA_OOB: adding kb (< 2 GiB) keeps them out of range
+        const unsigned voff = (dbg & 64) ? DMA_OOB : b_off[j] + b_kb;   // rows beyond N carry DMA_OOB: adding b_kb (< 2 GiB) keeps them out of range
         unsigned char* dst = stb + (wave * B_INSTR + j) * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, T2P_LDS_PTR(dst), 16, voff, 0, 0, 0);
       }
-      ib_st = ib_st + 1 == NSTB ? 0 : ib_st + 1;
-      if (TAPS == 1) {
-        ++ib_chunk;
+      if constexpr (NSTB == 2) ib_so ^= (unsigned)BSTAGE;
+      else ib_so = ib_so + BSTAGE == NSTB * BSTAGE ? 0u : ib_so + BSTAGE;
+      if constexpr (TAPS == 1) {
+        ++ib_chunk; b_kb += BK * 2;
       } else {
-        ++ib_tap;
-        if (ib_tap == TAPS) { ib_tap = 0; ++ib_chunk; }
+        ++ib_tap; b_kb += Ctot2;
+        if (ib_tap == TAPS) {
+          asm volatile("");
+          ++ib_chunk;
+          if (MODE == 1 && ib_chunk >= nch) { b_kb = (unsigned)(((long)TAPS * Ctot + (ib_chunk - nch) * BK) * 2); ib_tap = TAPS - 1; }
+          else { ib_tap = 0; b_kb += (unsigned)(BK * 2) - (unsigned)TAPS * Ctot2; }
+        }
       }
     }
   };
@@ -1239,6 +1315,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   issue(0, 2);
   if (AA > 1 && nk > 1) issue(1, AB > 1 ? 2 : 0);
   if (AA > 2 && nk > 2) issue(2, 2);
+  unsigned ra_so = 0, rb_so = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // outstanding after A(kt), B(kt) in issue order: symmetric ring: the min(AA - 1, nk - 1 - kt) younger tiles (the tail of
     // the loop has fewer); asymmetric (AB == AA - 1): only A(kt + 1 .. kt + AA - 1)
@@ -1258,8 +1335,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
     // front of every ds_read that may alias an in-flight LDS-DMA write and drain the ring.  The
     // reads of k-step s+1 are in flight while the MFMAs of step s run (lgkmcnt counts LDS ops in
     // order: <= TI + TJ outstanding means step s has landed).
-    const unsigned sa_off = lds_base + (unsigned)((kt % NST) * ASTAGE);
-    const unsigned sb_off = lds_base + (unsigned)((kt % NSTB) * BSTAGE);
+    const unsigned sa_off = lds_base + ra_so, sb_off = lds_base + rb_so;      // ring stages of K-tile kt
+    if constexpr (NST == 2) ra_so ^= (unsigned)ASTAGE;
+    else ra_so = ra_so + ASTAGE == NST * ASTAGE ? 0u : ra_so + ASTAGE;
+    if constexpr (NSTB == 2) rb_so ^= (unsigned)BSTAGE;
+    else rb_so = rb_so + BSTAGE == NSTB * BSTAGE ? 0u : rb_so + BSTAGE;
     if constexpr (MF16) {
       // fragments: B of k-step 0 / 1 (4 column tiles each), A low / high half (4 row tiles each)
       u32x4_t B0[4], B1[4], AL[4], AH[4];
@@ -1721,6 +1801,7 @@ static bool dma_eligible(const GemmParams& p) {
   if (p.a_up && p.taps != 9) return false;
   if (p.c_nchw) return false;
   if (((long)p.M + 256) * std::max(p.lda0, p.lda1) * 2 >= (1L << 31)) return false;   // 32-bit offset arithmetic
+  if ((long)p.M + 512 >= (1L << 24) || std::max(p.lda0, p.lda1) * 2 >= (1L << 24)) return false;   // row * stride in one 24-bit multiply
   const long a_rows = (p.taps == 9 || p.a_up) ? (long)(p.M / (p.H * p.W)) * (p.a_up ? (p.H / 2) * (p.W / 2) : p.H * p.W) : p.M;
   const long lim = (1L << 31) - 64;
   if (a_rows * p.lda0 * 2 >= lim || (p.A1 && a_rows * p.lda1 * 2 >= lim)) return false;
@@ -1842,7 +1923,7 @@ void set_gemm_midsplit(bool on) { g_midsplit = on; }
 
 DmaPlan dma_plan(const GemmParams& p) {
   const long z = (long)p.nz0 * p.nz1;
-  const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps;
+  const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps + (p.CX0 + p.CX1) / 64;
   const bool can_split = p.ws && z == 1;
   auto fits = [&](int ns) { return (size_t)ns * p.M * p.N * 4 <= p.ws_bytes; };
   const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * z;
@@ -1886,6 +1967,11 @@ DmaPlan dma_plan(const GemmParams& p) {
   // same tile with three K-tiles in flight, 128 KiB of LDS)
   if (geom == 2 && g_deep_ring && (long)tiles * nsplit * z <= num_cus()) geom = 4;
   return {geom, nsplit};
+}
+bool g_fuse_shortcut = true;
+void set_gemm_fuse_shortcut(bool on) { g_fuse_shortcut = on; }
+bool gemm_can_fuse_shortcut(const GemmParams& p) {
+  return g_fuse_shortcut && dma_eligible(p) && p.taps == 9 && !p.a_up;
 }
 static bool dma_uses_splitk(const GemmParams& p) { return dma_plan(p).nsplit > 1; }
 static int dma_pick_geom(const GemmParams& p) { return dma_plan(p).geom; }
@@ -1960,7 +2046,7 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
     T2P_HIP_CHECK(hipEventCreate(&rec.a));
     T2P_HIP_CHECK(hipEventCreate(&rec.b));
     rec.flops = MODE == 3 ? 2.0 * Mq * p.N * 4.0 * (p.C0 + p.C1)          // the multiplications this launch executes
-                          : 2.0 * p.M * p.N * (double)p.taps * (p.C0 + p.C1) * p.nz0 * p.nz1;
+                          : 2.0 * p.M * p.N * ((double)p.taps * (p.C0 + p.C1) + p.CX0 + p.CX1) * p.nz0 * p.nz1;
     rec.kind = p.taps == 9 ? 0 : 1;
     static const std::string kname = std::string("gemm_dma_kernel<") + (dtype_of<TC>::value == DT_F16 ? "f16_t" : "bf16_t") + ", " +
                                      std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) +
@@ -1988,7 +2074,7 @@ static int halo_a_stride(int BM, int W) { return (BM + 2 * W + 32) * 64; }
 
 // the LDS-halo kernel applies: a 3x3 convolution at full resolution whose tiles are whole image rows of one sample
 static bool conv_halo_eligible(const GemmParams& p, const DmaPlan& plan) {
-  if (!g_conv_halo || p.taps != 9 || p.a_up || plan.nsplit != 1 || (plan.geom != 1 && plan.geom != 3)) return false;
+  if (!g_conv_halo || p.X0 || p.taps != 9 || p.a_up || plan.nsplit != 1 || (plan.geom != 1 && plan.geom != 3)) return false;
   if (g_dma_ring != 2 || p.nz0 * p.nz1 != 1) return false;
   const int BM = plan.geom == 1 ? 256 : 512, HW = p.H * p.W;
   if (p.W % 16 != 0 || p.W > 128 || HW % BM != 0 || p.M % HW != 0) return false;
@@ -2224,6 +2310,15 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
   T2P_REQUIRE(((uintptr_t)p.A0 % 16) == 0 && ((uintptr_t)p.Bw % 16) == 0 && ((uintptr_t)p.A1 % 16) == 0,
               "operands must be 16-byte aligned");
   T2P_REQUIRE((long)(p.M + 127) / 128 < 65536, "M too large for grid.y");
+  if (p.X0 || p.X1 || p.CX0 || p.CX1) {
+    GemmParams q = p;
+    q.X0 = q.X1 = nullptr; q.CX0 = q.CX1 = 0;
+    T2P_REQUIRE(p.X0 && p.CX0 > 0 && p.CX0 % 64 == 0 && p.CX1 % 64 == 0 && (p.X1 != nullptr) == (p.CX1 > 0), "shortcut segment: whole 64-channel K-tiles");
+    T2P_REQUIRE(gemm_can_fuse_shortcut(q), "shortcut segment: only on the LDS-DMA 3x3 convolution (ask gemm_can_fuse_shortcut)");
+    T2P_REQUIRE(((uintptr_t)p.X0 % 16) == 0 && ((uintptr_t)p.X1 % 16) == 0 && p.ldx0 % 8 == 0 && p.ldx1 % 8 == 0, "shortcut segment: 16-byte aligned rows");
+    T2P_REQUIRE(((long)p.M + 512) * std::max(p.ldx0, p.ldx1) * 2 < (1L << 31) - 64 && std::max(p.ldx0, p.ldx1) * 2 < (1L << 24), "shortcut segment: 32-bit offsets");
+    T2P_REQUIRE(p.ldb >= 9L * (p.C0 + p.C1) + p.CX0 + p.CX1, "shortcut segment: weight rows hold 9 (C0 + C1) + CX0 + CX1 columns");
+  }
   if (g_thin_conv && thin_conv_eligible(p)) {
     // the head convolution: timed as "conv on the register-staged kernel" by the profile hooks' kind 2
     ProfRec rec;

@@ -109,6 +109,13 @@ struct GemmParams {
   const void* Bw4 = nullptr;
   long ldb4 = 0;
   int up_phase = 0;          // set by launch_gemm: 1 + phase of a MODE 3 launch
+  // optional, taps == 9 at full resolution on the LDS-DMA kernels (gemm_can_fuse_shortcut): CX0 + CX1 more K columns read at
+  // the output pixel itself from X0 | X1 (compute dtype), weights at K index 9 * (C0 + C1) + c -- the 1x1 shortcut of a
+  // residual block folded into its second convolution
+  const void* X0 = nullptr;
+  const void* X1 = nullptr;
+  int CX0 = 0, CX1 = 0;
+  long ldx0 = 0, ldx1 = 0;
   int M = 0, N = 0;
   // batching over blockIdx.z = z0 * nz1 + z1
   int nz0 = 1, nz1 = 1;
@@ -138,6 +145,7 @@ struct GemmParams {
 
 int launch_gemm(const GemmParams& p, hipStream_t stream);
 bool gemm_fuses_col_stats(const GemmParams& p);
+bool gemm_can_fuse_shortcut(const GemmParams& p);   // p without X0 / X1: would launch_gemm take the extra K segment?
 bool gemm_fuses_geglu(const GemmParams& p);
 bool gemm_fuses_col_stats_lowp(const GemmParams& p);
 void set_gemm_dma(bool on);
@@ -151,6 +159,7 @@ void set_gemm_thin_conv(bool on);
 void set_gemm_conv_halo(bool on);
 void set_gemm_up4(bool on);
 void set_gemm_deep_ring(bool on);
+void set_gemm_fuse_shortcut(bool on);
 extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible
 extern bool g_lowp_h1;         // engine: block-internal conv0 output stored in the compute dtype
 extern bool g_lowp_residual;   // engine: residual stream between blocks in the compute dtype (f16 mode)
