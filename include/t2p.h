@@ -224,6 +224,10 @@ int t2p_profile_dominant(double* out4, char* name, int name_len);
 /* after t2p_profile_end: the fused-attention launches of that region (CrossAttention.forward, model/attention.py:181-191,
  * self and text cross-attention): out3 = {ms, flops (4 nq nk d per head), launches} */
 int t2p_profile_attention(double* out3);
+/* after t2p_profile_end: the GEMM / convolution launches of that region by operand shape, as CSV text
+ * "kind,M,N,K,taps,batch,launches,ms,flops" (kind as in out9; K "a+b" = a channels per tap + b shortcut columns;
+ * taps negative = gathered from the half-resolution map).  T2P_ERR_INVALID when the buffer is too small */
+int t2p_profile_shapes(char* buf, int len);
 
 #ifdef __cplusplus
 }

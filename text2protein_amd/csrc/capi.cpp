@@ -472,6 +472,13 @@ int t2p_profile_attention(double* out3) {
   API_END
 }
 
+int t2p_profile_shapes(char* buf, int len) {
+  API_BEGIN
+  T2P_REQUIRE(buf && len > 0, "null argument");
+  return profile_shapes(buf, len);
+  API_END
+}
+
 int t2p_profile_dominant(double* out4, char* name, int name_len) {
   API_BEGIN
   T2P_REQUIRE(out4 && name && name_len > 0, "null argument");

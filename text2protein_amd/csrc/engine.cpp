@@ -442,7 +442,7 @@ int Engine::finalize() {
       }
       T2P_TRY(upload_linear(p + ".Conv_1.weight", p + ".Conv_1.bias", co, 9 * co, &l.conv1, true));
       if (l.has_conv2) T2P_TRY(upload_linear(p + ".Conv_2.weight", p + ".Conv_2.bias", co, ci, &l.conv2));
-      if (l.has_conv2 && !l.up && !l.down && cfg_.compute_dtype != DT_F32 && ci % 64 == 0 && co % 64 == 0) {
+      if (l.has_conv2 && !l.up && cfg_.compute_dtype != DT_F32 && ci % 64 == 0 && co % 64 == 0) {
         // h + shortcut(x) = [conv1 | conv2] applied to [3x3 window of a1 | x] (layers.py:322-327): one K loop, one fp32 sum
         const HostTensor* w1 = host(p + ".Conv_1.weight", {co, co, 3, 3});
         const HostTensor* w2 = host(p + ".Conv_2.weight", {co, ci, 1, 1});
@@ -692,10 +692,16 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
   pc.bias_n = L.conv1.b; pc.rows_per_batch = Ho * Wo;
   pc.alpha = cfg_.skip_rescale ? 0.70710678118654752440f : 1.f;
   bool fused_shortcut = false;
-  if (L.conv1x.w && (x.lowp || xraw) && x.C % 64 == 0 && (!skip || skip->C % 64 == 0) && gemm_can_fuse_shortcut(pc)) {
+  void* xpooled = nullptr;
+  if (L.conv1x.w && (L.down || x.lowp || xraw) && x.C % 64 == 0 && (!skip || skip->C % 64 == 0) && gemm_can_fuse_shortcut(pc)) {
     fused_shortcut = true;
     pc.Bw = L.conv1x.w; pc.ldb = L.conv1x.K; pc.bias_n = L.conv1x.b;
-    if (xraw) {
+    if (L.down) {                     // the shortcut of a down block reads the 2x2-averaged input (layers.py:313-315)
+      xpooled = pool_.get((size_t)rows_out * Cin * dtype_size(dt));
+      if (!xpooled) return T2P_ERR_HIP;
+      T2P_TRY(launch_pool2x2(x.p, xpooled, dt, B, x.H, x.W, Cin, s, x.lowp));
+      pc.X0 = xpooled; pc.CX0 = Cin; pc.ldx0 = Cin;
+    } else if (xraw) {
       pc.X0 = xraw; pc.CX0 = Cin; pc.ldx0 = Cin;
     } else {
       pc.X0 = x.p; pc.CX0 = x.C; pc.ldx0 = x.C;
@@ -752,7 +758,7 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
   T2P_TRY(gemm_stats(pc, &o_stats, s));
   pool_.put(a1);
   pool_.put(rbuf);
-  if (fused_shortcut) pool_.put(xraw);
+  if (fused_shortcut) { pool_.put(xraw); pool_.put(xpooled); }
   *out = Act{o, Cout, Ho, Wo, o_stats, olp};
   return T2P_OK;
 }

@@ -16,6 +16,8 @@
 // k-group s is the 16 bytes at [row][32 s + 16 (lane >> 5)], for both element widths.
 #include <algorithm>
 #include <array>
+#include <cstdio>
+#include <cstring>
 #include <map>
 #include <string>
 #include <type_traits>
@@ -142,7 +144,11 @@ template <typename TC> __device__ inline float4 res_load4(const float* R, long i
 #define T2P_PART_HOST (T2P_GEMM_PART <= 0)
 #define T2P_PART_DMA (T2P_GEMM_PART != 0)
 
-struct ProfRec { hipEvent_t a, b; double flops; int kind; const char* name; double bytes; };
+struct ProfRec { hipEvent_t a, b; double flops; int kind; const char* name; double bytes; int M = 0, N = 0, K = 0, taps = 0, z = 0; };
+inline void prof_shape(ProfRec& r, const GemmParams& p) {
+  r.M = p.M; r.N = p.N; r.K = p.C0 + p.C1; r.taps = p.a_up ? -p.taps : p.taps; r.z = p.nz0 * p.nz1;
+  if (p.CX0 + p.CX1) r.K = r.K * 1000000 + p.CX0 + p.CX1;      // shortcut segment: printed as K+KX
+}
 struct DmaPlan { int geom, nsplit; };
 extern bool g_prof_on;
 extern std::vector<ProfRec> g_prof;
@@ -1688,6 +1694,20 @@ int profile_attention(double out[3]) {
   return T2P_OK;
 }
 
+static std::map<std::string, std::array<double, 3>> g_shapes;    // "kind,M,N,K,taps,z" -> {launches, ms, flops} of the last region
+// the launches of the region closed by the last profile_end, one line per operand shape:
+// kind,M,N,K,taps (negative: gathered from the half-resolution map),batch,launches,ms,flops
+int profile_shapes(char* buf, int len) {
+  std::string t = "kind,M,N,K,taps,batch,launches,ms,flops\n";
+  for (auto& kv : g_shapes) {
+    char line[256];
+    std::snprintf(line, sizeof line, "%s,%.0f,%.4f,%.6g\n", kv.first.c_str(), kv.second[0], kv.second[1], kv.second[2]);
+    t += line;
+  }
+  if ((int)t.size() + 1 > len) { set_last_error("profile_shapes: buffer too small"); return T2P_ERR_INVALID; }
+  std::memcpy(buf, t.c_str(), t.size() + 1);
+  return T2P_OK;
+}
 void profile_begin() {
   for (ProfRec& r : g_prof_attn) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   g_prof_attn.clear();
@@ -1702,11 +1722,19 @@ int profile_end(double out[3][3]) {
   g_prof_on = false;
   for (int k = 0; k < 3; ++k) out[k][0] = out[k][1] = out[k][2] = 0;
   std::map<std::string, std::array<double, 4>> per;
+  g_shapes.clear();
   for (ProfRec& r : g_prof) {
     T2P_HIP_CHECK(hipEventSynchronize(r.b));
     float ms = 0.f;
     T2P_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
     out[r.kind][0] += ms; out[r.kind][1] += r.flops; out[r.kind][2] += 1;
+    {
+      char key[128];
+      if (r.K >= 1000000) std::snprintf(key, sizeof key, "%d,%d,%d,%d+%d,%d,%d", r.kind, r.M, r.N, r.K / 1000000, r.K % 1000000, r.taps, r.z);
+      else std::snprintf(key, sizeof key, "%d,%d,%d,%d,%d,%d", r.kind, r.M, r.N, r.K, r.taps, r.z);
+      auto& e = g_shapes[key];
+      e[0] += 1; e[1] += ms; e[2] += r.flops;
+    }
     if (r.kind == 0 && r.name) {
       auto& e = per[r.name];
       e[0] += ms; e[1] += r.flops; e[2] += 1; e[3] += r.bytes;
@@ -1749,6 +1777,7 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
   if (g_prof_on) {
     T2P_HIP_CHECK(hipEventCreate(&rec.a));
     T2P_HIP_CHECK(hipEventCreate(&rec.b));
+    prof_shape(rec, p);
     rec.flops = 2.0 * p.M * p.N * (double)p.taps * (p.C0 + p.C1) * p.nz0 * p.nz1;
     rec.kind = p.taps == 9 ? 2 : 1;
     rec.name = nullptr;
@@ -2045,6 +2074,7 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
   if (g_prof_on) {
     T2P_HIP_CHECK(hipEventCreate(&rec.a));
     T2P_HIP_CHECK(hipEventCreate(&rec.b));
+    prof_shape(rec, p);
     rec.flops = MODE == 3 ? 2.0 * Mq * p.N * 4.0 * (p.C0 + p.C1)          // the multiplications this launch executes
                           : 2.0 * p.M * p.N * ((double)p.taps * (p.C0 + p.C1) + p.CX0 + p.CX1) * p.nz0 * p.nz1;
     rec.kind = p.taps == 9 ? 0 : 1;
@@ -2094,6 +2124,7 @@ static int launch_conv_halo(const GemmParams& p, hipStream_t stream) {
   if (g_prof_on) {
     T2P_HIP_CHECK(hipEventCreate(&rec.a));
     T2P_HIP_CHECK(hipEventCreate(&rec.b));
+    prof_shape(rec, p);
     rec.flops = 2.0 * p.M * p.N * 9.0 * (p.C0 + p.C1);
     rec.kind = 0;
     static const std::string kname = std::string("conv_halo_kernel<") + (dtype_of<TC>::value == DT_F16 ? "f16_t" : "bf16_t") + ", " +
@@ -2325,6 +2356,8 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (g_prof_on) {
       T2P_HIP_CHECK(hipEventCreate(&rec.a));
       T2P_HIP_CHECK(hipEventCreate(&rec.b));
+      prof_shape(rec, p);
+    prof_shape(rec, p);
       rec.flops = 2.0 * p.M * p.N * 9.0 * p.C0; rec.kind = 2; rec.name = nullptr; rec.bytes = 0;
       T2P_HIP_CHECK(hipEventRecord(rec.a, stream));
     }

@@ -209,12 +209,17 @@ int launch_gn_stats(const GroupNormArgs& a, hipStream_t s) {
 }
 
 // ================================== GroupNorm apply (+SiLU, +2x2 mean) ==========================
-__device__ inline float silu_fast(float x) { return x * __frcp_rn(1.f + __expf(-x)); }
+// x * sigmoid(x) with the hardware's exp2 and reciprocal (1 ulp each; v_exp_f32, v_rcp_f32): 5 vector instructions per element --
+// the IEEE-rounded reciprocal alone expands to ~8, and this function is most of the arithmetic of the GroupNorm-apply pass.
+// exp2 of a large argument is +inf, its reciprocal 0: very negative x gives -0, not NaN
+__device__ inline float silu_fast(float x) {
+  return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
 
 // grid (pixel chunks, B, ceil(C / 1024)).  A thread keeps one 4-channel vector: its scale/shift
 // (rstd*gamma, beta - mean*rstd*gamma) are computed once, then it walks output pixels with 32-bit
 // indexing; consecutive lanes cover consecutive channels (coalesced 16-byte loads, 8/16-byte stores).
-static constexpr int GNA_PIX_PER_BLOCK = 64;
+static constexpr int GNA_PIX_PER_BLOCK = 64;      // 32 .. 256 measured equal within 0.3 % of a step
 bool g_gn_apply16 = true;     // 16-bit GroupNorm apply with 16-byte accesses (plan switch 17)
 
 template <typename TO, typename TI>

@@ -172,6 +172,7 @@ extern bool g_raw_copies;   // engine: feed 1x1 shortcut / proj_out GEMMs with c
 void profile_begin();
 int profile_end(double out[3][3]);
 int profile_dominant(double out[4], const char** name);
+int profile_shapes(char* buf, int len);
 bool prof_on();
 void prof_attention(hipEvent_t a, hipEvent_t b, double flops);
 int profile_attention(double out[3]);
