@@ -155,6 +155,12 @@ int t2p_op_conv3x3(int dtype, const void* x, int a_f32, const void* w, const flo
 int t2p_op_conv3x3_shortcut(int dtype, const void* a, const void* w, const float* bias, const void* x0, int CX0,
                             const void* x1, int CX1, float alpha, void* out, int c_f32, int batch, int H, int W, int C,
                             int Cout, void* stream);
+/* the network's input convolution (pre_conv, ncsnpp.py:230: 3x3, C = 5 or 8 input channels -> nf) straight from the NCHW fp32
+ * sample, in fp32 arithmetic: x [batch][C][H][W] fp32; w_tcn [3*3][C][nf] fp32 (tap-major); out NHWC [batch][H][W][nf] in
+ * out_dtype.  col_stats (optional; W % 64 == 0, nf | 256): [batch H W / 64][nf][2] fp32 = (sum, sum of squares) of the fp32
+ * results per 64-pixel chunk and channel -- what the first GroupNorm needs, so that it does not re-read the tensor */
+int t2p_op_input_conv(const float* x, const float* w_tcn, const float* bias, void* out, int out_dtype, int batch, int C,
+                      int H, int W, int nf, float* col_stats, void* stream);
 int t2p_op_groupnorm(const float* x0, const float* x1, int C0, int C1, int batch, int H, int W, int groups,
                      const float* gamma, const float* beta, float eps, int silu, int down, void* out, int dtype,
                      void* stream);

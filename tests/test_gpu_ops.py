@@ -485,3 +485,36 @@ def test_conv3x3_with_shortcut_segment(lib, geom):
     # shapes that are not on the LDS-DMA convolution are refused, not silently computed without the segment
     z = torch.zeros(1, 8, 8, 32, device="cuda", dtype=torch.float16)
     assert lib.t2p_op_conv3x3_shortcut(2, P(z), P(z), None, P(z), 32, None, 0, 1.0, P(z), 0, 1, 8, 8, 32, 32, None) != 0
+
+
+@pytest.mark.parametrize("C,nf,H,W", [(5, 256, 8, 128), (5, 128, 8, 64), (8, 128, 4, 128), (5, 64, 8, 64), (5, 256, 6, 40)])
+def test_input_conv_and_its_column_statistics(lib, C, nf, H, W):
+    """pre_conv (ncsnpp.py:230) from the NCHW fp32 sample, fp32 arithmetic; where the shape allows it the kernel also emits
+    the per-64-pixel column sums the first GroupNorm consumes: the same output bits with and without them, and the sums equal
+    those of the fp32 results."""
+    B = 2
+    g = torch.Generator().manual_seed(C * 1000 + nf + W)
+    x = torch.randn(B, C, H, W, generator=g) * 30.0
+    w = torch.randn(nf, C, 3, 3, generator=g) / (9 * C) ** 0.5
+    b = torch.randn(nf, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)       # NHWC
+    w_tcn = dev(w.permute(2, 3, 1, 0).reshape(9, C, nf).contiguous())
+    out32 = torch.full((B, H, W, nf), float("nan"), device="cuda")
+    check(lib, lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(out32), 0, B, C, H, W, nf, None, None))
+    torch.cuda.synchronize()
+    assert rel_l2(out32.cpu(), ref) < 1e-6
+    out16 = torch.full((B, H, W, nf), float("nan"), device="cuda", dtype=torch.float16)
+    check(lib, lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(out16), 2, B, C, H, W, nf, None, None))
+    torch.cuda.synchronize()
+    assert rel_l2(out16.float().cpu(), ref) < 3e-4          # fp32 result rounded once to f16
+    if W % 64 == 0:
+        cs = torch.full((B * H * W // 64, nf, 2), float("nan"), device="cuda")
+        o2 = torch.full_like(out16, float("nan"))
+        check(lib, lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(o2), 2, B, C, H, W, nf, P(cs), None))
+        torch.cuda.synchronize()
+        assert torch.equal(o2.cpu(), out16.cpu())
+        chunks = out32.cpu().double().reshape(-1, 64, nf)
+        assert rel_l2(cs[..., 0].cpu(), chunks.sum(1)) < 1e-6 and rel_l2(cs[..., 1].cpu(), (chunks ** 2).sum(1)) < 1e-6
+    else:   # refused, not silently wrong
+        cs = torch.zeros(B * H * W // 64 + 1, nf, 2, device="cuda")
+        assert lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(out16), 2, B, C, H, W, nf, P(cs), None) != 0

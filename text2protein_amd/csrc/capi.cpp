@@ -231,6 +231,13 @@ int t2p_op_conv3x3_shortcut(int dtype, const void* a, const void* w, const float
   API_END
 }
 
+int t2p_op_input_conv(const float* x, const float* w_tcn, const float* bias, void* out, int out_dtype, int batch, int C, int H, int W,
+                      int nf, float* col_stats, void* stream) {
+  API_BEGIN
+  return launch_pre_conv(x, w_tcn, bias, out, out_dtype, batch, C, H, W, nf, (hipStream_t)stream, col_stats);
+  API_END
+}
+
 int t2p_op_groupnorm(const float* x0, const float* x1, int C0, int C1, int batch, int H, int W, int groups,
                      const float* gamma, const float* beta, float eps, int silu, int down, void* out, int dtype,
                      void* stream) {

@@ -992,8 +992,15 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
   }
   const bool hlp = res_lowp() && (Cx == 5 || Cx == 8) && pre_conv_direct_;   // the residual stream starts here
   POOL_GET(h0, float*, (size_t)B * HW * nf_ * (hlp ? dtype_size(dtype()) : 4));
+  float* h0_stats = nullptr;
   if ((Cx == 5 || Cx == 8) && pre_conv_direct_) {
-    T2P_TRY(launch_pre_conv(x, pre_conv_direct_, pre_conv_.b, h0, hlp ? dtype() : DT_F32, B, Cx, L, L, nf_, s));
+    // 16-bit modes: the GroupNorm column statistics of h0 (read by the first block and, through the skip stack, by the last
+    // stage) come out of the input convolution instead of two passes over the tensor
+    if (hlp && g_fuse_gn_stats && pre_conv_fuses_col_stats(L, nf_) && !(g_gn_small && HW <= 64)) {
+      h0_stats = (float*)pool_.get((size_t)B * (HW / 64) * nf_ * 2 * 4);
+      if (!h0_stats) return T2P_ERR_HIP;
+    }
+    T2P_TRY(launch_pre_conv(x, pre_conv_direct_, pre_conv_.b, h0, hlp ? dtype() : DT_F32, B, Cx, L, L, nf_, s, h0_stats));
   } else {
     POOL_GET(xin, float*, (size_t)B * HW * cpad_ * 4);
     T2P_TRY(launch_nchw_to_nhwc(x, xin, B, Cx, HW, cpad_, s));
@@ -1017,7 +1024,7 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
   pool_.put(emb); pool_.put(t1); pool_.put(t2);
 
   std::vector<Act> hs;
-  Act h{h0, nf_, L, L, nullptr, h0_lowp};
+  Act h{h0, nf_, L, L, h0_stats, h0_lowp};
   hs.push_back(h);
   for (Stage& st : input_stages_) {
     T2P_TRY(run_stage(st, h, nullptr, B, s));

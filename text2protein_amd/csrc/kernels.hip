@@ -753,19 +753,22 @@ static constexpr int PRE_ROWS = 4;   // image rows per block: the per-thread wei
 
 template <int C, typename TO>
 __global__ __launch_bounds__(256) void pre_conv_kernel(const float* x, const float* w, const float* bias, TO* out, int B,
-                                                       int H, int W, int nf) {
+                                                       int H, int W, int nf, float* cstats) {
   constexpr int SEG = 32, ROW = 40;                    // patch rows padded to 16-byte multiples (34 used + 6)
   __shared__ __attribute__((aligned(16))) float patch[C][3][ROW];
-  const int segs = (W + SEG - 1) / SEG, rblks = (H + PRE_ROWS - 1) / PRE_ROWS;
+  __shared__ float red[2][256];                        // statistics of the pixel groups of one channel (nf < 256)
+  // cstats (optional; W % 64 == 0, nf <= 256): GroupNorm column statistics of the output in the layout of the GEMM epilogues,
+  // [B H W / 64][nf][2] = per 64-pixel chunk and channel (sum, sum of squares) of the fp32 values.  A block then walks the two
+  // 32-pixel segments of a chunk one after the other and its threads carry the sums across them.
+  const int nhalf = cstats ? 2 : 1;
+  const int segs = (W + SEG - 1) / SEG / nhalf, rblks = (H + PRE_ROWS - 1) / PRE_ROWS;
   const int seg = blockIdx.x % segs, yb = (blockIdx.x / segs) % rblks, b = blockIdx.x / (segs * rblks);
-  const int x0 = seg * SEG;
   // a thread owns one output channel (its 9 C weights in registers; w is [tap][c][nf], so a wavefront reads each
   // of them as one contiguous row) and 4 consecutive pixels at a time: the 3-tap window of 4 pixels is 6
   // consecutive patch values = two 16-byte LDS reads for 12 FMAs (a read per FMA made the kernel LDS-issue-bound).
   // With nf <= 128 the block splits the segment into pixel groups so that all 256 threads work.
   const int ngrp = nf >= 256 ? 1 : (256 / nf >= 8 ? 8 : 256 / nf);
   const int pg = SEG / ngrp;                           // pixels per group: 32, 16, 8 or 4
-  const int npx = min(SEG, W - x0);
   for (int co0 = 0; co0 < nf; co0 += 256) {
     const int co = co0 + (ngrp == 1 ? (int)threadIdx.x : (int)threadIdx.x % nf);
     const int grp = ngrp == 1 ? 0 : (int)threadIdx.x / nf;
@@ -775,6 +778,10 @@ __global__ __launch_bounds__(256) void pre_conv_kernel(const float* x, const flo
     for (int i = 0; i < C * 9; ++i) wr[i] = work ? w[(long)i * nf + co] : 0.f;
     const float bv = work ? bias[co] : 0.f;
     for (int y = yb * PRE_ROWS; y < min(H, (yb + 1) * PRE_ROWS); ++y) {
+     float ssum = 0.f, ssq = 0.f;
+     for (int half = 0; half < nhalf; ++half) {
+      const int x0 = (seg * nhalf + half) * SEG;
+      const int npx = min(SEG, W - x0);
       __syncthreads();                                 // the previous row's patch is no longer read
       for (int i = threadIdx.x; i < C * 3 * ROW; i += 256) {
         const int c = i / (3 * ROW), r = (i / ROW) % 3, col = i % ROW;
@@ -801,20 +808,39 @@ __global__ __launch_bounds__(256) void pre_conv_kernel(const float* x, const flo
         if (px + 1 < npx) o[(long)nf] = from_f32<TO>(a1);
         if (px + 2 < npx) o[2L * nf] = from_f32<TO>(a2);
         if (px + 3 < npx) o[3L * nf] = from_f32<TO>(a3);
+        ssum += (a0 + a1) + (a2 + a3);                 // (cstats: W % 64 == 0, so all four pixels exist)
+        ssq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
       }
+     }
+     if (cstats) {
+       // fold the pixel groups of a channel in a fixed order (bitwise reproducible), one store per channel
+       __syncthreads();
+       red[0][threadIdx.x] = ssum; red[1][threadIdx.x] = ssq;
+       __syncthreads();
+       if (work && grp == 0) {
+         float t0 = 0.f, t1 = 0.f;
+         for (int g = 0; g < ngrp; ++g) { t0 += red[0][g * nf + co - co0]; t1 += red[1][g * nf + co - co0]; }
+         const long chunk = (((long)b * H + y) * W + seg * 64) >> 6;
+         *(float2*)(cstats + (chunk * nf + co) * 2) = make_float2(t0, t1);
+       }
+     }
     }
   }
 }
 
+// the thread layout (a thread = one channel, pixel groups of 4) yields whole 64-pixel chunks without atomics when:
+bool pre_conv_fuses_col_stats(int W, int nf) { return W % 64 == 0 && nf <= 256 && 256 % nf == 0 && nf >= 32; }
+
 int launch_pre_conv(const float* x, const float* w, const float* bias, void* out, int out_dtype, int B, int C, int H, int W, int nf,
-                    hipStream_t s) {
+                    hipStream_t s, float* cstats) {
   T2P_REQUIRE(x && w && bias && out && B > 0 && nf > 0, "pre_conv arguments");
-  const int segs = (W + 31) / 32;
+  T2P_REQUIRE(!cstats || pre_conv_fuses_col_stats(W, nf), "pre_conv: column statistics need W % 64 == 0 and 64 | nf <= 256");
+  const int segs = (W + 31) / 32 / (cstats ? 2 : 1);
   dim3 grid((unsigned)((long)B * ((H + PRE_ROWS - 1) / PRE_ROWS) * segs));
 #define T2P_PRE(CC)                                                                                                        \
-  if (out_dtype == DT_F16) hipLaunchKernelGGL((pre_conv_kernel<CC, f16_t>), grid, dim3(256), 0, s, x, w, bias, (f16_t*)out, B, H, W, nf); \
-  else if (out_dtype == DT_BF16) hipLaunchKernelGGL((pre_conv_kernel<CC, bf16_t>), grid, dim3(256), 0, s, x, w, bias, (bf16_t*)out, B, H, W, nf); \
-  else hipLaunchKernelGGL((pre_conv_kernel<CC, float>), grid, dim3(256), 0, s, x, w, bias, (float*)out, B, H, W, nf);
+  if (out_dtype == DT_F16) hipLaunchKernelGGL((pre_conv_kernel<CC, f16_t>), grid, dim3(256), 0, s, x, w, bias, (f16_t*)out, B, H, W, nf, cstats); \
+  else if (out_dtype == DT_BF16) hipLaunchKernelGGL((pre_conv_kernel<CC, bf16_t>), grid, dim3(256), 0, s, x, w, bias, (bf16_t*)out, B, H, W, nf, cstats); \
+  else hipLaunchKernelGGL((pre_conv_kernel<CC, float>), grid, dim3(256), 0, s, x, w, bias, (float*)out, B, H, W, nf, cstats);
   switch (C) {
     case 5: T2P_PRE(5) break;
     case 8: T2P_PRE(8) break;

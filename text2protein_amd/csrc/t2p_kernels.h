@@ -59,7 +59,8 @@ int launch_pool2x2(const float* x, void* out, int dtype, int B, int H, int W, in
 
 // ---- pre_conv: 3x3, C in {5, 8} NCHW fp32 -> nf NHWC (fp32 or a 16-bit out_dtype); w = [9][C][nf] fp32 (tap-major, output channel contiguous) --
 int launch_pre_conv(const float* x, const float* w, const float* bias, void* out, int out_dtype, int B, int C, int H, int W, int nf,
-                    hipStream_t s);
+                    hipStream_t s, float* cstats = nullptr);
+bool pre_conv_fuses_col_stats(int W, int nf);
 
 // ---- NCHW fp32 (B,C,L,L) -> NHWC fp32 [B][L*L][Cpad], zero padded channels -----------------------
 int launch_nchw_to_nhwc(const float* x, float* out, int B, int C, int HW, int Cpad, hipStream_t s);
