@@ -1988,7 +1988,9 @@ DmaPlan dma_plan(const GemmParams& p) {
     if (can_split && g_force_nsplit > 1 && nk >= 2 * g_force_nsplit) nsplit = g_force_nsplit;
   } else if (g_splitk && can_split && tiles < 192 && nk >= 16) {
     // the tile grid cannot fill the chip and the K loop is long (low-resolution levels)
-    nsplit = std::min(std::min(nk / 4, (384 + tiles - 1) / tiles), 32);
+    // (tiles x splits ~ one workgroup per CU: a target of 256 measured 0.2 ms per step better than 384 at cfg2 and cfg3,
+    // 128 .. 192 and 320 .. 768 worse; at least 4 K-tiles per split, 2 .. 12 within noise)
+    nsplit = std::min(std::min(nk / 4, (256 + tiles - 1) / tiles), 32);
   }
   while (nsplit > 1 && !fits(nsplit)) --nsplit;
   // 128 x 128 tiles on at most one workgroup per CU: such a launch is bound by the latency of its K-steps (0.47 us each with
