@@ -179,6 +179,12 @@ int64_t t2p_op_attention_ws(int dtype, int batch, int heads, int nq, int nk);
 int t2p_op_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt,
                      int64_t ldvt, void* out, int batch, int heads, int nq, int nk, int d, float scale,
                      void* workspace, void* stream);
+/* self-attention on the output of ONE stacked projection (CrossAttention.forward with context = x, model/attention.py:
+ * 170-191): qkv [batch][n][ld] holds q | k | v in three column blocks of heads*d (head h at column h*d of its block);
+ * out [batch][n][heads*d].  V is read row-major -- the fused kernel transposes it on the way out of LDS -- so no
+ * separate V^T projection is needed.  16-bit dtypes, d in {32, 64, 128} only (anything else is refused) */
+int t2p_op_attention_qkv(int dtype, const void* qkv, int64_t ld, void* out, int batch, int heads, int n, int d,
+                         float scale, void* stream);
 int t2p_op_langevin(const float* x, const float* grad, const float* noise, const uint8_t* mask,
                     const float* x_initial, float* x_out, float* x_mean_out, int batch, int64_t per_sample,
                     float snr, float alpha, float* sums_out /* device float[2], may be NULL */, void* stream);

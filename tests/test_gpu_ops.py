@@ -518,3 +518,32 @@ def test_input_conv_and_its_column_statistics(lib, C, nf, H, W):
     else:   # refused, not silently wrong
         cs = torch.zeros(B * H * W // 64 + 1, nf, 2, device="cuda")
         assert lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(out16), 2, B, C, H, W, nf, P(cs), None) != 0
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("B,heads,n,d", [(2, 8, 1024, 64), (1, 4, 300, 128), (3, 8, 256, 32), (2, 8, 16, 64), (1, 2, 130, 64), (2, 8, 64, 64)])
+def test_self_attention_on_stacked_qkv(lib, dt, B, heads, n, d):
+    """t2p_op_attention_qkv: q | k | v as three column blocks of one projection output; V is consumed row-major through the
+    transposing LDS read (no V^T projection).  Against the softmax(q k^T) v of the rounded operands, ragged key counts included,
+    and equal to the V^T form of the same kernel within rounding of nothing (the same products in the same order)."""
+    g = torch.Generator().manual_seed(n * 7 + d)
+    C_ = heads * d
+    td = TDT[dt]
+    qkv = torch.randn(B, n, 3 * C_, generator=g).to(td)
+    q, k, v = (qkv[..., i * C_:(i + 1) * C_] for i in range(3))
+    scale = d ** -0.5
+    qh, kh, vh = (t.double().reshape(B, n, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(B, n, C_)
+    out = torch.full((B, n, C_), float("nan"), device="cuda", dtype=td)
+    check(lib, lib.t2p_op_attention_qkv(dt, P(dev(qkv)), 3 * C_, P(out), B, heads, n, d, scale, None))
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu(), ref) < (8e-3 if dt == 1 else 1e-3)
+    npad = (n + 7) // 8 * 8
+    vt = torch.zeros(B, C_, npad, dtype=td)
+    vt[:, :, :n] = v.transpose(1, 2)
+    ws = torch.empty(lib.t2p_op_attention_ws(dt, B, heads, n, n), dtype=torch.uint8, device="cuda")
+    out2 = torch.empty(B, n, C_, device="cuda", dtype=td)
+    check(lib, lib.t2p_op_attention(dt, P(dev(q.contiguous())), C_, P(dev(k.contiguous())), C_, P(dev(vt)), npad, P(out2), B, heads,
+                                    n, n, d, scale, P(ws), None))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), out2.cpu())

@@ -72,6 +72,7 @@ SIGNATURES = {
     "t2p_op_softmax": (_i, [_vp, _i64, _vp, _i64, _i, _i64, _i, _f, _vp]),
     "t2p_op_geglu": (_i, [_vp, _vp, _i, _i64, _i, _vp]),
     "t2p_op_attention_ws": (_i64, [_i, _i, _i, _i, _i]),
+    "t2p_op_attention_qkv": (_i, [_i, _vp, _i64, _vp, _i, _i, _i, _i, _f, _vp]),
     "t2p_op_attention": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "t2p_op_langevin": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _f, _f, _vp, _vp]),
     "t2p_op_langevin_norms": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp]),

@@ -14,6 +14,13 @@
 // One workgroup = 4 wavefronts x 32 queries; K and V^T tiles of 64 keys are staged
 // global -> registers -> LDS (padded rows: conflict-free ds_read_b128 / ds_read_b64),
 // double-buffered.
+//
+// VROW (self-attention): V is taken ROW-major, [key][head * D + d] -- the third column block of the block's one q|k|v
+// projection GEMM -- instead of the separately projected V^T.  Its tile is staged like the K tile and the A fragment of
+// O^T = V^T P^T comes out of LDS through ds_read_b64_tr_b16, gfx950's transposing read: per 16-lane group a block of 4 rows
+// (keys) x 16 columns (d) is delivered column-major, i.e. lane (d) receives its 4 keys -- exactly the fragment's halves.
+// Lane 4 q + p of a group supplies the address of key row q, columns 4 p .. 4 p + 3; rows are VRS bytes apart, an
+// odd multiple of 16 dwords, which puts the four key rows of a block into four different 16-bank windows: conflict-free.
 #include "t2p_kernels.h"
 
 namespace t2p {
@@ -47,18 +54,22 @@ template <> __device__ inline uint32_t pack2<f16_t>(float a, float b) {
 struct FlashArgs {
   const void* q; long ldq; long sq_b;       // [B][nq][ldq], head h at column h * D
   const void* k; long ldk; long sk_b;       // [B][nk][ldk]
-  const void* vt; long ldvt; long svt_b;    // [B][heads * D][ldvt]
+  const void* vt; long ldvt; long svt_b;    // [B][heads * D][ldvt]; VROW: v = [B][nk][ldvt], head h at column h * D
   void* out; long ldo; long so_b;           // [B][nq][ldo]
   int nq, nk;
   float scale_log2e;                        // scale * log2(e)
 };
 
-template <typename TC, int D>
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+
+template <typename TC, int D, bool VROW>
 __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const FlashArgs a) {
   constexpr int BKV = 64;
   constexpr int KS = D * 2 + 16;            // K tile row stride (bytes)
   constexpr int VS = BKV * 2 + 8;           // V^T tile row stride (bytes)
-  constexpr int KBYTES = BKV * KS, VBYTES = D * VS;
+  constexpr int VRS = D == 32 ? 64 : (D == 64 ? 192 : 320);   // VROW: V tile row stride (bytes): an odd multiple of 16 dwords
+  static_assert((VRS / 4) % 32 == 16 && VRS >= D * 2 && VRS % 16 == 0, "row stride of the transposed-read V tile");
+  constexpr int KBYTES = BKV * KS, VBYTES = VROW ? BKV * VRS : D * VS;
   constexpr int NS = D / 16;                // k-steps of the score product
   constexpr int NT = D / 32;                // 32-row tiles of O^T
   constexpr int KV = D / 32;                // staging vectors per thread for each of K and V^T
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const FlashArgs a) {
   const int q0 = blockIdx.x * 128 + wave * 32;
   const TC* Q = (const TC*)a.q + (long)b * a.sq_b + (long)head * D;
   const TC* K = (const TC*)a.k + (long)b * a.sk_b + (long)head * D;
-  const TC* VT = (const TC*)a.vt + (long)b * a.svt_b + (long)head * D * a.ldvt;
+  const TC* VT = (const TC*)a.vt + (long)b * a.svt_b + (VROW ? (long)head * D : (long)head * D * a.ldvt);
 
   // Q fragments (B operand of S^T = K Q^T): lane (query lr, half lh) holds Q[q][16 s + 8 lh .. + 7]
   uint4 qf[NS];
@@ -91,6 +102,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const FlashArgs a) {
       const int row = idx / (D / 8), ch = idx % (D / 8);
       const int key = key0 + row;
       rk[i] = key < a.nk ? *(const uint4*)(K + (long)key * a.ldk + ch * 8) : make_uint4(0, 0, 0, 0);
+      if constexpr (VROW) {                   // same (key, chunk) as the K tile; keys beyond nk are zero (their P is)
+        rv[i] = key < a.nk ? *(const uint4*)(VT + (long)key * a.ldvt + ch * 8) : make_uint4(0, 0, 0, 0);
+        continue;
+      }
       const int vrow = idx >> 3, vch = idx & 7;
       const int kc = key0 + vch * 8;          // first key of this chunk
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -116,6 +131,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const FlashArgs a) {
       const int idx = tid + 256 * i;
       const int row = idx / (D / 8), ch = idx % (D / 8);
       *(uint4*)(kb + row * KS + ch * 16) = rk[i];
+      if constexpr (VROW) {
+        *(uint4*)(vb + row * VRS + ch * 16) = rv[i];
+        continue;
+      }
       const int vrow = idx >> 3, vch = idx & 7;
       uint2* dst = (uint2*)(vb + vrow * VS + vch * 16);     // rows are 8-byte aligned only
       dst[0] = make_uint2(rv[i].x, rv[i].y);
@@ -194,10 +213,19 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const FlashArgs a) {
         pf.w = pack2<TC>(sacc[8 * ks + 6], sacc[8 * ks + 7]);
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) {
-          const unsigned char* vr = vb + (tt * 32 + lr) * VS + (sub * 32 + 16 * ks + 4 * lh) * 2;
-          const uint2 v0 = *(const uint2*)vr;            // keys 16 ks + 4 lh + 0..3
-          const uint2 v1 = *(const uint2*)(vr + 16);     // keys 16 ks + 8 + 4 lh + 0..3
-          AMma<TC>::run(make_uint4(v0.x, v0.y, v1.x, v1.y), pf, o[tt]);
+          if constexpr (VROW) {
+            // group (lane >> 4) = (d half dh, key half lh); lane 4 q + p of it addresses key row q, d columns 4 p .. 4 p + 3
+            const unsigned char* vr = vb + (sub * 32 + 16 * ks + 4 * lh + ((lane & 15) >> 2)) * VRS +
+                                      (tt * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+            const uint2 v0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)vr));
+            const uint2 v1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(vr + 8 * VRS)));
+            AMma<TC>::run(make_uint4(v0.x, v0.y, v1.x, v1.y), pf, o[tt]);
+          } else {
+            const unsigned char* vr = vb + (tt * 32 + lr) * VS + (sub * 32 + 16 * ks + 4 * lh) * 2;
+            const uint2 v0 = *(const uint2*)vr;            // keys 16 ks + 4 lh + 0..3
+            const uint2 v1 = *(const uint2*)(vr + 16);     // keys 16 ks + 8 + 4 lh + 0..3
+            AMma<TC>::run(make_uint4(v0.x, v0.y, v1.x, v1.y), pf, o[tt]);
+          }
         }
       }
     }
@@ -223,10 +251,10 @@ __global__ __launch_bounds__(256, 2) void attn_flash_kernel(const FlashArgs a) {
   }
 }
 
-template <typename TC, int D>
+template <typename TC, int D, bool VROW>
 static int launch_flash_t(const FlashArgs& a, int B, int heads, hipStream_t s) {
-  constexpr int smem = 2 * (64 * (D * 2 + 16) + D * (64 * 2 + 8));
-  auto kern = attn_flash_kernel<TC, D>;
+  constexpr int smem = 2 * (64 * (D * 2 + 16) + (VROW ? 64 * (D == 32 ? 64 : (D == 64 ? 192 : 320)) : D * (64 * 2 + 8)));
+  auto kern = attn_flash_kernel<TC, D, VROW>;
   T2P_TRY(ensure_dynamic_lds((const void*)kern, smem));
   dim3 grid((a.nq + 127) / 128, heads, B);
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -250,8 +278,9 @@ bool attention_flash_eligible(int dtype, int d, long ldq, long ldk, long ldvt, l
   return ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0;
 }
 
+// v_rowmajor: `vt` is V itself, [B][nk][ldvt] with head h at column h * d (ldvt its row stride), not the transposed projection
 int launch_attention_flash(int dtype, const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt,
-                           void* out, int B, int heads, int nq, int nk, int d, float scale, hipStream_t s) {
+                           void* out, int B, int heads, int nq, int nk, int d, float scale, hipStream_t s, bool v_rowmajor) {
   T2P_REQUIRE(attention_flash_eligible(dtype, d, ldq, ldk, ldvt, (long)heads * d), "flash attention: unsupported shape");
   T2P_REQUIRE(q && k && vt && out && B > 0 && heads > 0 && nq > 0 && nk > 0, "flash attention arguments");
   T2P_REQUIRE(scale > 0.f, "flash attention: the running maximum is taken on unscaled scores (scale must be positive)");
@@ -260,11 +289,11 @@ int launch_attention_flash(int dtype, const void* q, long ldq, const void* k, lo
   FlashArgs a;
   a.q = q; a.ldq = ldq; a.sq_b = (long)nq * ldq;
   a.k = k; a.ldk = ldk; a.sk_b = (long)nk * ldk;
-  a.vt = vt; a.ldvt = ldvt; a.svt_b = (long)heads * d * ldvt;
+  a.vt = vt; a.ldvt = ldvt; a.svt_b = v_rowmajor ? (long)nk * ldvt : (long)heads * d * ldvt;
   a.out = out; a.ldo = (long)heads * d; a.so_b = (long)nq * heads * d;
   a.nq = nq; a.nk = nk;
   a.scale_log2e = scale * 1.44269504088896340736f;
-#define T2P_FLASH(TC, DD) return launch_flash_t<TC, DD>(a, B, heads, s)
+#define T2P_FLASH(TC, DD) return v_rowmajor ? launch_flash_t<TC, DD, true>(a, B, heads, s) : launch_flash_t<TC, DD, false>(a, B, heads, s)
   if (dtype == DT_BF16) {
     if (d == 32) T2P_FLASH(bf16_t, 32);
     if (d == 64) T2P_FLASH(bf16_t, 64);

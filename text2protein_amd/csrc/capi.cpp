@@ -333,6 +333,17 @@ int t2p_op_attention(int dtype, const void* q, int64_t ldq, const void* k, int64
   API_END
 }
 
+int t2p_op_attention_qkv(int dtype, const void* qkv, int64_t ld, void* out, int batch, int heads, int n, int d, float scale, void* stream) {
+  API_BEGIN
+  const long C = (long)heads * d;
+  T2P_REQUIRE(qkv && out && ld >= 3 * C, "attention_qkv arguments");
+  T2P_REQUIRE(attention_flash_eligible(dtype, d, ld, ld, ld, C), "attention_qkv: 16-bit dtypes, head dimension 32 / 64 / 128, ld % 8 == 0");
+  const size_t es = dtype_size(dtype);
+  return launch_attention_flash(dtype, qkv, ld, (const char*)qkv + C * es, ld, (const char*)qkv + 2 * C * es, ld, out, batch, heads, n, n, d,
+                                scale, (hipStream_t)stream, true);
+  API_END
+}
+
 int t2p_op_langevin(const float* x, const float* grad, const float* noise, const uint8_t* mask, const float* x_initial,
                     float* x_out, float* x_mean_out, int batch, int64_t per_sample, float snr, float alpha,
                     float* sums_out, void* stream) {
@@ -426,6 +437,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 21) { set_gemm_up4(value != 0); return T2P_OK; }
   if (key == 22) { set_gemm_deep_ring(value != 0); return T2P_OK; }
   if (key == 23) { set_gemm_fuse_shortcut(value != 0); return T2P_OK; }
+  if (key == 25) { g_qkv_fused = value != 0; return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) {
 #ifndef T2P_ABLATION

@@ -20,6 +20,7 @@ bool g_gn_small = true;
 bool g_lowp_residual = true;
 bool g_raw_copies = true;
 bool g_flash_attention = true;
+bool g_qkv_fused = true;      // self-attention: one q | k | v projection, V read row-major by the fused kernel (plan switch 25)
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 const char* get_last_error() { return g_last_error.c_str(); }
@@ -479,6 +480,17 @@ int Engine::finalize() {
       T2P_TRY(upload_linear(p + ".proj_out.weight", p + ".proj_out.bias", ci, ci, &l.proj_out));
       T2P_TRY(upload_stack2(t + ".attn1.to_q.weight", "", t + ".attn1.to_k.weight", "", ci, ci, false, false, &l.a1_qk));
       T2P_TRY(upload_linear(t + ".attn1.to_v.weight", "", ci, ci, &l.a1_v));
+      if (cfg_.compute_dtype != DT_F32) {      // the fused attention kernel reads V row-major: q | k | v from one GEMM
+        const HostTensor* wq = host(t + ".attn1.to_q.weight", {ci, ci});
+        const HostTensor* wk = host(t + ".attn1.to_k.weight", {ci, ci});
+        const HostTensor* wv = host(t + ".attn1.to_v.weight", {ci, ci});
+        if (!wq || !wk || !wv) return T2P_ERR_STATE;
+        std::vector<float> m = wq->data;
+        m.insert(m.end(), wk->data.begin(), wk->data.end());
+        m.insert(m.end(), wv->data.begin(), wv->data.end());
+        T2P_TRY(upload_matrix(pool_, m, cfg_.compute_dtype, &l.a1_qkv.w));
+        l.a1_qkv.N = 3 * ci; l.a1_qkv.K = ci; l.a1_qkv.b = nullptr;
+      }
       T2P_TRY(upload_linear(t + ".attn1.to_out.0.weight", t + ".attn1.to_out.0.bias", ci, ci, &l.a1_out));
       T2P_TRY(upload_linear(t + ".attn2.to_q.weight", "", ci, ci, &l.a2_q));
       T2P_TRY(upload_linear(t + ".attn2.to_k.weight", "", ci, ctx, &l.a2_k));
@@ -852,7 +864,13 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   POOL_GET(o, void*, (size_t)rows * C * es);
   // attn1: self-attention
   T2P_TRY(launch_layernorm(t, L.ln1.gamma, L.ln1.beta, ln, dt, rows, C, 1e-5f, s, tl));
-  {
+  if (g_qkv_fused && L.a1_qkv.w && g_flash_attention && attention_flash_eligible(dt, d, 3 * C, 3 * C, 3 * C, C)) {
+    POOL_GET(qkv, char*, (size_t)rows * 3 * C * es);
+    T2P_TRY(linear(ln, false, L.a1_qkv, rows, qkv, false, nullptr, 1.f, s, false));
+    T2P_TRY(launch_attention_flash(dt, qkv, 3 * C, qkv + (size_t)C * es, 3 * C, qkv + (size_t)2 * C * es, 3 * C, o, B, heads, n, n, d, scale, s,
+                                   true));
+    pool_.put(qkv);
+  } else {
     POOL_GET(qk, char*, (size_t)rows * 2 * C * es);
     T2P_TRY(linear(ln, false, L.a1_qk, rows, qk, false, nullptr, 1.f, s, false));
     POOL_GET(vt, void*, (size_t)B * C * npad * es);

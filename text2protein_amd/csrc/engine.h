@@ -64,6 +64,7 @@ struct Layer {
   // attn (AttnBlockpp): NIN_0|NIN_1 stacked, NIN_2, NIN_3
   DevLinear qk, v, out;
   // st (SpatialTransformer)
+  DevLinear a1_qkv;   // 16-bit modes: to_q | to_k | to_v stacked, one projection GEMM for the self-attention
   DevLinear proj_in, proj_out, a1_qk, a1_v, a1_out, a2_q, a2_k, a2_v, a2_out, ff1, ff2;
   DevNorm ln1, ln2, ln3;
   void* ctx_k = nullptr;   // [B][T][C]      compute dtype (set_context)

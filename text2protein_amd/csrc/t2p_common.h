@@ -160,6 +160,7 @@ void set_gemm_conv_halo(bool on);
 void set_gemm_up4(bool on);
 void set_gemm_deep_ring(bool on);
 void set_gemm_fuse_shortcut(bool on);
+extern bool g_qkv_fused;
 extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible
 extern bool g_lowp_h1;         // engine: block-internal conv0 output stored in the compute dtype
 extern bool g_lowp_residual;   // engine: residual stream between blocks in the compute dtype (f16 mode)

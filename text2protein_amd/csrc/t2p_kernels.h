@@ -109,7 +109,7 @@ int launch_scale(float* x, long n, float a, hipStream_t s);
 // ---- fused attention (attention.hip): 16-bit dtypes, head dim 32 / 64 / 128 -------------------------
 bool attention_flash_eligible(int dtype, int d, long ldq, long ldk, long ldvt, long ldo);
 int launch_attention_flash(int dtype, const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt,
-                           void* out, int B, int heads, int nq, int nk, int d, float scale, hipStream_t s);
+                           void* out, int B, int heads, int nq, int nk, int d, float scale, hipStream_t s, bool v_rowmajor = false);
 
 int launch_convert(const float* in, void* out, int dtype, long n, hipStream_t s);
 int launch_gather_label(const int* labels, const int* step_counter, const float* table, float* out, int B, int N,
