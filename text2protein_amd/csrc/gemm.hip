@@ -2088,7 +2088,9 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
     {
       const double Ct = p.C0 + p.C1, z = (double)p.nz0 * p.nz1;
       const double a_rows = p.a_up ? p.M / 4.0 : p.M;                    // up-sampling convs gather from the half-resolution map
-      rec.bytes = z * (a_rows * Ct * 2 + (double)p.N * p.taps * Ct * 2 + (double)p.M * (p.geglu ? p.N / 2 : p.N) * (p.c_f32 ? 4 : 2) +
+      const double Cx = p.CX0 + p.CX1;                                   // shortcut segment: its input rows and weights once
+      rec.bytes = z * (a_rows * Ct * 2 + (double)p.N * p.taps * Ct * 2 + (double)p.M * Cx * 2 + (double)p.N * Cx * 2 +
+                       (double)p.M * (p.geglu ? p.N / 2 : p.N) * (p.c_f32 ? 4 : 2) +
                        (p.R ? (double)p.M * p.N * (p.r_lowp ? 2 : 4) / (p.r_up ? 4 : 1) : 0.0) + (p.bias_bn ? (double)(p.M / p.rows_per_batch) * p.N * 4 : 0.0));
     }
     T2P_HIP_CHECK(hipEventRecord(rec.a, stream));

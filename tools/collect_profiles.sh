@@ -14,5 +14,9 @@ echo "[7/9] SQ pass 2"; rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_LDS_BANK
 echo "[8/9] TCC"; rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc_${TAG}_tcc -- $B > gpurun_out/pmc_tcc.log 2>&1
 echo "[9/9] cfg3 kernel trace"; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_cfg3 -- $B --workload cfg3 > gpurun_out/prof_${TAG}_cfg3.log 2>&1
 for w in cfg3 cfg4 cfg5; do python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-f32 > gpurun_out/bench_$w.json 2>/dev/null; done
+for w in cfg2 cfg3; do
+  python bench.py --workload $w --steps 8 --warmup 3 --no-cpu-baseline --no-f32 --shapes gpurun_out/shapes_$w.csv > /dev/null 2>&1
+  python tools/shapes_table.py gpurun_out/shapes_$w.csv --top 80 > gpurun_out/${TAG}_shapes_$w.md
+done
 find gpurun_out -name "*_kernel_trace.csv" -path "*pmc_*" -delete    # keep the merge-back under the size cap
 echo done
