@@ -83,6 +83,20 @@ def build(force: bool = False, verbose: bool = True, ablation: bool = False) -> 
     lib, stamp = (LIB_ABLATION, LIB_ABLATION + ".srchash") if ablation else (LIB, STAMP)
     if not force and os.path.exists(lib) and _read(stamp) == source_hash(ablation):
         return lib
+    # one builder at a time: the ranks of a multi-process job all arrive here when the library is stale; the first builds,
+    # the others wait on the lock and then find the stamp in place
+    import fcntl
+    with open(lib + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and os.path.exists(lib) and _read(stamp) == source_hash(ablation):
+                return lib
+            return _build_locked(lib, stamp, verbose, ablation)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(lib: str, stamp: str, verbose: bool, ablation: bool) -> str:
     hipcc = _hipcc()
     objs = []
     procs = []
