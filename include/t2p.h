@@ -219,9 +219,10 @@ int t2p_op_apply_mask(float* x, const uint8_t* mask, const float* x_initial, int
  * out9 = {LDS-DMA conv3x3: ms, flops, launches; other GEMMs: ...; conv3x3 on the register-staged kernel: ...} since t2p_profile_begin */
 int t2p_profile_begin(void);
 /* Plan switches for tests and A/B measurements: they select between kernel geometries / fusions that all
- * produce correct results (key 0 LDS-DMA GEMM on/off, 2 tile geometry, 3 split-K, 4..15 individual fusions;
- * text2protein_amd/csrc/capi.cpp).  Key 1 is the timing-only ablation mask of the LDS-DMA kernel: its bits
- * 128 / 256 (DMA issue order, results unchanged) are always accepted, the bits that skip work and so produce
+ * produce correct results (key 0 LDS-DMA GEMM on/off, 2 tile geometry, 3 split-K, 4..25 individual fusions and
+ * kernel forms -- the full list with one line each: tools/README.md; text2protein_amd/csrc/capi.cpp).  Key 1 is the
+ * timing-only ablation mask of the LDS-DMA kernel: its bits 128 / 256 (DMA issue order) and 4096 (LDS-staged instead of
+ * register epilogue), results unchanged, are always accepted, the bits that skip work and so produce
  * WRONG results exist only in a library built with -DT2P_ABLATION (python -m text2protein_amd.build --ablation)
  * and are refused (status 1) by the product build. */
 int t2p_debug_set(int key, int value);

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define T2P_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-static constexpr unsigned DMA_OOB = 0x80000000u;   // >= any num_records we accept -> zeros
+[[maybe_unused]] static constexpr unsigned DMA_OOB = 0x80000000u;   // >= any num_records we accept -> zeros
 
 // erf-GELU for the fused GEGLU epilogue (16-bit outputs only): Abramowitz-Stegun 7.1.26, |error| of
 // erf <= 1.5e-7 -- far below the fp16 / bf16 rounding of the result -- in a dozen VALU operations
