@@ -804,7 +804,7 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
 
   const int row_w = m0 + wm * (BM / WM);                 // first row of the wave tile (128 rows = 8 tiles of 16)
   // up_phase (MODE 3): rows are pixels of the half-resolution map; row (b, yl, xl) is stored at output pixel (b, 2 yl + py, 2 xl + px)
-  const int upp = p.up_phase;
+  const int upp = p.up_phase == 5 ? 1 + (int)blockIdx.y : p.up_phase;     // 5: all four phases in one launch, the phase on grid.y
   const int Mrows = upp ? p.M >> 2 : p.M;
   const int Wl = p.W >> 1, HWl = (p.H >> 1) * (p.W >> 1);
   const int col0 = n0 + wn * (BN / WN) + 8 * g4;         // this lane's channels: [col0, col0 + 8) and [col0 + 32, col0 + 40)
@@ -1050,7 +1050,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   }
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int z0 = blockIdx.y / p.nz1, z1 = blockIdx.y % p.nz1;
+  // MODE 3: the four output phases of an up-sampling convolution are the y dimension of one grid (up_phase == 5): a phase
+  // launch of a low-resolution level has 64 workgroups, the four together fill the chip
+  const int upk = MODE == 3 ? (p.up_phase == 5 ? 1 + (int)blockIdx.y : p.up_phase) : 0;
+  const int z0 = MODE == 3 ? 0 : blockIdx.y / p.nz1, z1 = MODE == 3 ? 0 : blockIdx.y % p.nz1;
 
   const int Ctot = p.C0 + p.C1;
   const int nch = (Ctot + BK - 1) / BK;
@@ -1068,7 +1071,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   // half-resolution map (the taps that read the same source pixel are summed into one weight on the host): rows are the
   // M / 4 source pixels, tap (ty, tx) reads pixel (yl + ty - 1 + py, xl + tx - 1 + px), the epilogue scatters row
   // (b, yl, xl) to output pixel (b, 2 yl + py, 2 xl + px).  4 / 9 of the multiplications of the gather form (MODE 2).
-  const int up_py = MODE == 3 ? ((p.up_phase - 1) >> 1) : 0, up_px = MODE == 3 ? ((p.up_phase - 1) & 1) : 0;
+  const int up_py = MODE == 3 ? ((upk - 1) >> 1) : 0, up_px = MODE == 3 ? ((upk - 1) & 1) : 0;
   const int Mq = MODE == 3 ? p.M >> 2 : p.M;            // rows of this launch
   const int HWq = MODE == 3 ? Hs * Ws : HW, Wq = MODE == 3 ? Ws : p.W, Hq = MODE == 3 ? Hs : p.H;
 
@@ -1076,7 +1079,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   // readfirstlane'd scalars so that hipcc keeps them in SGPRs (no waterfall loop around the DMA).
   const long a_rows = MODE == 0 ? (long)p.M : (long)(p.M / HW) * Hs * Ws;
   const TC* A0p = (const TC*)p.A0 + (long)z0 * p.sA_z0 + (long)z1 * p.sA_z1;
-  const TC* Bp = (const TC*)p.Bw + (long)z0 * p.sB_z0 + (long)z1 * p.sB_z1;
+  const TC* Bp = (const TC*)p.Bw + (long)z0 * p.sB_z0 + (long)z1 * p.sB_z1 +
+                 ((MODE == 3 && p.up_phase == 5) ? (long)(upk - 1) * p.N * p.ldb : 0L);       // phase weights [4][N][ldb]
   const int a0_bytes = (int)(((a_rows - 1) * p.lda0 + p.C0) * 2);
   const int a1_bytes = p.A1 ? (int)(((a_rows - 1) * p.lda1 + p.C1) * 2) : 0;
   const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bp, (int)((((long)p.N - 1) * p.ldb + (long)TAPS * Ctot + nchx * BK) * 2));
@@ -2071,13 +2075,13 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
   const int Mq = MODE == 3 ? p.M / 4 : p.M;               // MODE 3: one output phase per launch
   const int tiles_m = (Mq + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int nsplit = MODE == 3 ? 1 : dma_plan(p).nsplit;
-  dim3 grid(tiles_m * tiles_n, p.nz0 * p.nz1, nsplit);
+  dim3 grid(tiles_m * tiles_n, MODE == 3 ? (p.up_phase == 5 ? 4 : 1) : p.nz0 * p.nz1, nsplit);
   ProfRec rec;
   if (g_prof_on) {
     T2P_HIP_CHECK(hipEventCreate(&rec.a));
     T2P_HIP_CHECK(hipEventCreate(&rec.b));
     prof_shape(rec, p);
-    rec.flops = MODE == 3 ? 2.0 * Mq * p.N * 4.0 * (p.C0 + p.C1)          // the multiplications this launch executes
+    rec.flops = MODE == 3 ? 2.0 * Mq * p.N * 4.0 * (p.C0 + p.C1) * (p.up_phase == 5 ? 4 : 1)     // the multiplications this launch executes
                           : 2.0 * p.M * p.N * ((double)p.taps * (p.C0 + p.C1) + p.CX0 + p.CX1) * p.nz0 * p.nz1;
     rec.kind = p.taps == 9 ? 0 : 1;
     static const std::string kname = std::string("gemm_dma_kernel<") + (dtype_of<TC>::value == DT_F16 ? "f16_t" : "bf16_t") + ", " +
@@ -2168,13 +2172,10 @@ int launch_dma_mode(const GemmParams& p, hipStream_t stream) {
     if (up4_eligible(p, plan)) {
       GemmParams q = p;
       q.ldb = p.ldb4;
-      for (int ph = 0; ph < 4; ++ph) {
-        q.up_phase = ph + 1;
-        q.Bw = (const TC*)p.Bw4 + (long)ph * p.N * p.ldb4;
-        if (plan.geom == 1) T2P_TRY((launch_dma_geom<TC, 3, 256, 256, 2, 4, 2, 2, true, true>(q, stream)));
-        else T2P_TRY((launch_dma_geom<TC, 3, 512, 128, 4, 2, 2, 2, true, true>(q, stream)));
-      }
-      return T2P_OK;
+      q.Bw = p.Bw4;
+      q.up_phase = 5;                  // all four phases in one launch (grid.y = phase)
+      if (plan.geom == 1) return launch_dma_geom<TC, 3, 256, 256, 2, 4, 2, 2, true, true>(q, stream);
+      return launch_dma_geom<TC, 3, 512, 128, 4, 2, 2, 2, true, true>(q, stream);
     }
   }
   if constexpr (MODE == 1) {

@@ -108,7 +108,7 @@ struct GemmParams {
   // the layer as four 2x2 convolutions on the source map (4 / 9 of the multiplications)
   const void* Bw4 = nullptr;
   long ldb4 = 0;
-  int up_phase = 0;          // set by launch_gemm: 1 + phase of a MODE 3 launch
+  int up_phase = 0;          // set by launch_gemm: 1 + phase of a MODE 3 launch, 5 = all four phases (the phase is blockIdx.y)
   // optional, taps == 9 at full resolution on the LDS-DMA kernels (gemm_can_fuse_shortcut): CX0 + CX1 more K columns read at
   // the output pixel itself from X0 | X1 (compute dtype), weights at K index 9 * (C0 + C1) + c -- the 1x1 shortcut of a
   // residual block folded into its second convolution
