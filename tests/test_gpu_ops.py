@@ -487,7 +487,7 @@ def test_conv3x3_with_shortcut_segment(lib, geom):
     assert lib.t2p_op_conv3x3_shortcut(2, P(z), P(z), None, P(z), 32, None, 0, 1.0, P(z), 0, 1, 8, 8, 32, 32, None) != 0
 
 
-@pytest.mark.parametrize("C,nf,H,W", [(5, 256, 8, 128), (5, 128, 8, 64), (8, 128, 4, 128), (5, 64, 8, 64), (5, 256, 6, 40)])
+@pytest.mark.parametrize("C,nf,H,W", [(5, 256, 8, 128), (5, 128, 8, 64), (8, 128, 4, 128), (5, 64, 8, 64), (5, 256, 6, 40), (8, 256, 18, 64)])
 def test_input_conv_and_its_column_statistics(lib, C, nf, H, W):
     """pre_conv (ncsnpp.py:230) from the NCHW fp32 sample, fp32 arithmetic; where the shape allows it the kernel also emits
     the per-64-pixel column sums the first GroupNorm consumes: the same output bits with and without them, and the sums equal
@@ -503,21 +503,27 @@ def test_input_conv_and_its_column_statistics(lib, C, nf, H, W):
     check(lib, lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(out32), 0, B, C, H, W, nf, None, None))
     torch.cuda.synchronize()
     assert rel_l2(out32.cpu(), ref) < 1e-6
-    out16 = torch.full((B, H, W, nf), float("nan"), device="cuda", dtype=torch.float16)
-    check(lib, lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(out16), 2, B, C, H, W, nf, None, None))
-    torch.cuda.synchronize()
-    assert rel_l2(out16.float().cpu(), ref) < 3e-4          # fp32 result rounded once to f16
-    if W % 64 == 0:
-        cs = torch.full((B * H * W // 64, nf, 2), float("nan"), device="cuda")
-        o2 = torch.full_like(out16, float("nan"))
-        check(lib, lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(o2), 2, B, C, H, W, nf, P(cs), None))
-        torch.cuda.synchronize()
-        assert torch.equal(o2.cpu(), out16.cpu())
-        chunks = out32.cpu().double().reshape(-1, 64, nf)
-        assert rel_l2(cs[..., 0].cpu(), chunks.sum(1)) < 1e-6 and rel_l2(cs[..., 1].cpu(), (chunks ** 2).sum(1)) < 1e-6
-    else:   # refused, not silently wrong
-        cs = torch.zeros(B * H * W // 64 + 1, nf, 2, device="cuda")
-        assert lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(out16), 2, B, C, H, W, nf, P(cs), None) != 0
+    # 16-bit output: on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, plan switch 26; W % 64 == 0) and on the FMA kernel
+    try:
+        for sw in (1, 0):
+            check(lib, lib.t2p_debug_set(26, sw))
+            out16 = torch.full((B, H, W, nf), float("nan"), device="cuda", dtype=torch.float16)
+            check(lib, lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(out16), 2, B, C, H, W, nf, None, None))
+            torch.cuda.synchronize()
+            assert rel_l2(out16.float().cpu(), ref) < 3e-4          # fp32 result rounded once to f16
+            if W % 64 == 0:
+                cs = torch.full((B * H * W // 64, nf, 2), float("nan"), device="cuda")
+                o2 = torch.full_like(out16, float("nan"))
+                check(lib, lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(o2), 2, B, C, H, W, nf, P(cs), None))
+                torch.cuda.synchronize()
+                assert torch.equal(o2.cpu(), out16.cpu())
+                chunks = out32.cpu().double().reshape(-1, 64, nf)
+                assert rel_l2(cs[..., 0].cpu(), chunks.sum(1)) < 1e-6 and rel_l2(cs[..., 1].cpu(), (chunks ** 2).sum(1)) < 1e-6
+            else:   # refused, not silently wrong
+                cs = torch.zeros(B * H * W // 64 + 1, nf, 2, device="cuda")
+                assert lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(out16), 2, B, C, H, W, nf, P(cs), None) != 0
+    finally:
+        lib.t2p_debug_set(26, 1)
 
 
 @pytest.mark.parametrize("dt", [1, 2])

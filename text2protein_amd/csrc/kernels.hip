@@ -828,6 +828,121 @@ __global__ __launch_bounds__(256) void pre_conv_kernel(const float* x, const flo
   }
 }
 
+// ---- the input convolution on the fp32 matrix pipe (16-bit modes) ---------------------------------------------------
+// out[pixel][channel] = sum_k patch[pixel][k] w[k][channel], k = tap * C + c (K = 45 or 72), as v_mfma_f32_32x32x2_f32:
+// fp32 operands and accumulation like the FMA kernel above (another summation order: 1e-7), at the matrix pipe's fp32 rate
+// instead of scalar FMAs.  A wave owns one image row of a 4-row x 64-pixel block tile: two wave tiles of 32 pixels x 32 NT
+// channels (NT = 4 accumulator tiles; 256 channels are two passes).  Operands per k-step (k = 2 s + (lane >> 5)):
+//   A: lane's pixel (lane & 31), value patch[c][row + dy][px + dx] from the block's LDS patch (6 input rows x 66 columns);
+//   B: channel (lane & 31) * NT + j for accumulator tile j -- the NT channels of a lane are CONSECUTIVE, so w[k] is read as
+//      NT contiguous floats and a pixel's output row is stored in 2 NT-byte pieces, 32 lanes covering the whole row.
+// The weights ([K padded to even][nf] fp32, 47 KiB at nf = 256) stay in LDS while the block walks 16 image rows.
+// GroupNorm column statistics: a wave's two tiles are one 64-pixel chunk; per-lane sums over its 16 + 16 pixel rows, the two
+// lane halves folded by one shuffle, lanes 0 .. 31 store them.
+typedef float pf32x16 __attribute__((ext_vector_type(16)));
+static constexpr int PREM_ROWS = 16;     // image rows per block
+
+template <int C, int NT, typename TO>
+__global__ __launch_bounds__(256, 2) void pre_conv_mfma_kernel(const float* x, const float* w, const float* bias, TO* out, int B, int H,
+                                                              int W, int nf, float* cstats) {
+  constexpr int K = 9 * C, KP = (K + 1) & ~1, NP = 32 * NT, PW = 66, PR = 6;      // NP: channels of one pass over the K loop
+  extern __shared__ __attribute__((aligned(16))) float psm[];
+  float* wl = psm;                          // [KP][nf]
+  float* patch = psm + KP * nf;             // [C][PR][PW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, kh = lane >> 5;
+  const int segs = W / 64, rblks = (H + PREM_ROWS - 1) / PREM_ROWS;
+  const int seg = blockIdx.x % segs, rb = (blockIdx.x / segs) % rblks, b = blockIdx.x / (segs * rblks);
+  const int x0 = seg * 64;
+  for (int i = tid; i < KP * nf; i += 256) wl[i] = i < K * nf ? w[i] : 0.f;
+  for (int y0 = rb * PREM_ROWS; y0 < min(H, (rb + 1) * PREM_ROWS); y0 += 4) {
+    __syncthreads();                        // the previous rows' patch is no longer read (and, the first time, wl is complete below)
+    for (int i = tid; i < C * PR * PW; i += 256) {
+      const int c = i / (PR * PW), r = (i / PW) % PR, col = i % PW;
+      const int sy = y0 + r - 1, sx = x0 + col - 1;
+      patch[i] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[(((long)b * C + c) * H + sy) * W + sx] : 0.f;
+    }
+    __syncthreads();
+    const int y = y0 + wave;
+    if (y >= H) continue;                   // wave-uniform
+    // 256 channels are two passes of 128 (64 accumulator registers each: with all 128 the k loop's operands spill)
+#pragma unroll 1
+    for (int cb = 0; cb < nf; cb += NP) {
+      const int ch0 = cb + l32 * NT;        // this lane's NT consecutive channels
+      float bv[NT], ssum[NT], ssq[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) { bv[j] = bias[ch0 + j]; ssum[j] = 0.f; ssq[j] = 0.f; }
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        pf32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+        const float* prow = patch + wave * PW + half * 32 + l32;     // input row y - 1 + dy is patch row wave + dy
+        const float* wrow = wl + kh * nf + ch0;
+        // operands of k-step s (k = 2 s + kh: both candidates are compile-time constants, the lane half selects)
+        auto load = [&](int s, float& a, float (&bw)[NT]) __attribute__((always_inline)) {
+          const int k0 = 2 * s, k1 = 2 * s + 1;
+          const int o0 = k0 < K ? ((k0 % C) * PR + (k0 / C) / 3) * PW + (k0 / C) % 3 : 0;
+          const int o1 = k1 < K ? ((k1 % C) * PR + (k1 / C) / 3) * PW + (k1 / C) % 3 : 0;
+          a = prow[kh ? o1 : o0];
+          if (k1 >= K && kh) a = 0.f;                                  // the padded k of an odd K
+          const float* wr = wrow + 2 * s * nf;
+          if constexpr (NT % 4 == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; j += 4) { const float4 t = *(const float4*)(wr + j); bw[j] = t.x; bw[j + 1] = t.y; bw[j + 2] = t.z; bw[j + 3] = t.w; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < NT; j += 2) { const float2 t = *(const float2*)(wr + j); bw[j] = t.x; bw[j + 1] = t.y; }
+          }
+        };
+        float a_n, bw_n[NT];
+        load(0, a_n, bw_n);
+#pragma unroll
+        for (int s = 0; s < KP / 2; ++s) {
+          const float a = a_n;
+          float bw[NT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bw[j] = bw_n[j];
+          if (s + 1 < KP / 2) load(s + 1, a_n, bw_n);                 // one step ahead: its LDS latency under this step's MFMAs
+          asm volatile("" ::: "memory");                              // (and no further: the compiler would hoist every step's reads)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[j], acc[j], 0, 0, 0);
+        }
+        // accumulator register v of tile j: pixel row (v >> 2) * 8 + kh * 4 + (v & 3), channel ch0 + j
+        TO* obase = out + (((long)b * H + y) * W + x0 + half * 32) * nf + ch0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int pr = (v >> 2) * 8 + kh * 4 + (v & 3);
+          union { TO e[NT]; uint2 u2; unsigned u1; } o;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const float t = acc[j][v] + bv[j];
+            o.e[j] = from_f32<TO>(t);
+            ssum[j] += t; ssq[j] += t * t;
+          }
+          TO* dst = obase + (long)pr * nf;
+          if constexpr (NT == 4) *(uint2*)dst = o.u2;
+          else *(unsigned*)dst = o.u1;
+        }
+      }
+      if (cstats) {
+        const long chunk = (((long)b * H + y) * W + x0) >> 6;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float s0 = ssum[j] + __shfl_xor(ssum[j], 32, 64), s1 = ssq[j] + __shfl_xor(ssq[j], 32, 64);
+          if (kh == 0) *(float2*)(cstats + (chunk * nf + ch0 + j) * 2) = make_float2(s0, s1);
+        }
+      }
+    }
+  }
+}
+
+bool g_pre_conv_mfma = true;      // plan switch 26
+static bool pre_conv_mfma_ok(int out_dtype, int C, int W, int nf) {
+  return g_pre_conv_mfma && out_dtype != DT_F32 && (C == 5 || C == 8) && W % 64 == 0 && (nf == 256 || nf == 128 || nf == 64);
+}
+
 // the thread layout (a thread = one channel, pixel groups of 4) yields whole 64-pixel chunks without atomics when:
 bool pre_conv_fuses_col_stats(int W, int nf) { return W % 64 == 0 && nf <= 256 && 256 % nf == 0 && nf >= 32; }
 
@@ -835,6 +950,25 @@ int launch_pre_conv(const float* x, const float* w, const float* bias, void* out
                     hipStream_t s, float* cstats) {
   T2P_REQUIRE(x && w && bias && out && B > 0 && nf > 0, "pre_conv arguments");
   T2P_REQUIRE(!cstats || pre_conv_fuses_col_stats(W, nf), "pre_conv: column statistics need W % 64 == 0 and 64 | nf <= 256");
+  if (pre_conv_mfma_ok(out_dtype, C, W, nf)) {
+    const int KP = (9 * C + 1) & ~1;
+    const int smem = (KP * nf + C * 6 * 66) * 4;
+    dim3 gridm((unsigned)((long)B * ((H + PREM_ROWS - 1) / PREM_ROWS) * (W / 64)));
+#define T2P_PREM(CC, NTT, TT)                                                                        \
+  {                                                                                                  \
+    auto kern = pre_conv_mfma_kernel<CC, NTT, TT>;                                                   \
+    T2P_TRY(ensure_dynamic_lds((const void*)kern, smem));                                            \
+    hipLaunchKernelGGL(kern, gridm, dim3(256), smem, s, x, w, bias, (TT*)out, B, H, W, nf, cstats);      \
+  }
+#define T2P_PREM_C(NTT, TT) if (C == 5) T2P_PREM(5, NTT, TT) else T2P_PREM(8, NTT, TT)
+#define T2P_PREM_T(NTT) if (out_dtype == DT_F16) { T2P_PREM_C(NTT, f16_t) } else { T2P_PREM_C(NTT, bf16_t) }
+    if (nf >= 128) { T2P_PREM_T(4) } else { T2P_PREM_T(2) }
+#undef T2P_PREM_T
+#undef T2P_PREM_C
+#undef T2P_PREM
+    T2P_HIP_CHECK(hipGetLastError());
+    return T2P_OK;
+  }
   const int segs = (W + 31) / 32 / (cstats ? 2 : 1);
   dim3 grid((unsigned)((long)B * ((H + PRE_ROWS - 1) / PRE_ROWS) * segs));
 #define T2P_PRE(CC)                                                                                                        \
