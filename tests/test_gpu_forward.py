@@ -125,3 +125,30 @@ def test_gn_apply_16byte_kernel_is_bit_identical():
     finally:
         lib.t2p_debug_set(17, 1)
     assert torch.isfinite(b).all() and torch.equal(a, b)
+
+
+def test_groupnorm_folded_statistics_in_the_apply_launch():
+    """Maps of <= 4096 pixels whose GroupNorm statistics arrive as column sums: finalize and apply in one launch (plan switch
+    27: a block folds the sums of its own 64-channel slab) against the separate finalize launch -- the same double-precision
+    sums, only their order inside a group differs, so the scores agree to rounding of the statistics (f16 engine, 32^2 and
+    16^2 maps, one- and two-source inputs)."""
+    from text2protein_amd import _lib, synth
+    from helpers import cfg_smallC
+    lib = _lib.load()
+    cfg = cfg_smallC()
+    m = make_model(cfg, 5, "f16")
+    B = 3
+    L = cfg.data.max_res_num
+    x = (torch.from_numpy(synth.normal(8, "x", B * 5 * L * L).reshape(B, 5, L, L)) * 10.0).cuda()
+    ctx = synth.synth_context(B, 7, cfg.model.context_dim, 2).cuda()
+    labels = torch.tensor([0, 4, 9]).cuda()
+    try:
+        lib.t2p_debug_set(27, 0)
+        a = m(x, labels, ctx).cpu()
+        lib.t2p_debug_set(27, 1)
+        b = m(x, labels, ctx).cpu()
+    finally:
+        lib.t2p_debug_set(27, 1)
+    d = rel_l2(b, a)
+    print(f"GroupNorm statistics folded in the apply launch vs separate finalize: rel-L2 = {d:.3e}, bit-equal = {torch.equal(a, b)}")
+    assert torch.isfinite(b).all() and d < 1e-4

@@ -17,7 +17,7 @@ using namespace t2p;
     return T2P_ERR_STATE;                              \
   }
 
-namespace t2p { extern bool g_pre_conv_mfma; }
+namespace t2p { extern bool g_pre_conv_mfma, g_gn_apply_cols; }
 extern "C" {
 
 const char* t2p_last_error(void) { return get_last_error(); }
@@ -440,6 +440,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 23) { set_gemm_fuse_shortcut(value != 0); return T2P_OK; }
   if (key == 25) { g_qkv_fused = value != 0; return T2P_OK; }
   if (key == 26) { t2p::g_pre_conv_mfma = value != 0; return T2P_OK; }
+  if (key == 27) { t2p::g_gn_apply_cols = value != 0; return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) {
 #ifndef T2P_ABLATION

@@ -619,6 +619,20 @@ int Engine::group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps,
   a.x0 = x.p; a.x1 = x1 ? x1->p : nullptr; a.C0 = x.C; a.C1 = x1 ? x1->C : 0;
   a.B = B; a.HW = x.H * x.W; a.G = n.G; a.eps = eps;
   const bool have_cols = x.cstats && (!x1 || x1->cstats) && a.HW % 64 == 0;
+  if (have_cols && !raw_out) {
+    // maps of <= 4096 pixels: fold the column statistics and normalise in one launch
+    GroupNormApplyArgs g;
+    g.x0 = a.x0; g.x1 = a.x1; g.C0 = a.C0; g.C1 = a.C1; g.B = B; g.H = x.H; g.W = x.W; g.G = n.G;
+    g.gamma = n.gamma; g.beta = n.beta; g.silu = silu; g.down = down; g.dtype = dtype(); g.x0_lowp = x.lowp;
+    g.cs0 = x.cstats; g.cs1 = x1 ? x1->cstats : nullptr; g.eps = eps;
+    if (gn_apply_cols_eligible(g)) {
+      POOL_GET(o, void*, (size_t)B * a.HW * C * dtype_size(dtype()));
+      g.out = o;
+      T2P_TRY(launch_gn_apply_cols(g, s));
+      *out = o;
+      return T2P_OK;
+    }
+  }
   const int nparts = gn_num_chunks(a.HW) * ((C + 1023) / 1024);
   POOL_GET(stats, float*, (size_t)B * n.G * 2 * 4);
   float* partial = nullptr;

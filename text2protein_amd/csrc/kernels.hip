@@ -325,6 +325,93 @@ __global__ __launch_bounds__(256) void gn_apply16_kernel(GroupNormApplyArgs a, i
   for (; p < p_hi; p += ppi) apply(*(const u4*)(src + (long)p * ld), p);
 }
 
+// Finalize + apply in one launch for maps of <= 4096 pixels (their GroupNorm is two latency-bound launches otherwise): grid
+// (pixel parts, C / 64, B).  A block folds the column sums of ITS 64 channels only ([HW / 64 chunks][64][2] floats, <= 32 KiB,
+// L2-resident: the producing epilogue has just written them) in double precision and a fixed order, derives mean / rstd of the
+// slab's 64 / cpg groups, then normalises its share of the sample's pixels like gn_apply16_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_cols_kernel(GroupNormApplyArgs a, int pix_per_block) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  __shared__ double red[2][4][64];
+  __shared__ float gstat[2][64];
+  const int C = a.C0 + a.C1, HW = a.H * a.W, nchunk = HW >> 6, cpg = C / a.G;
+  const int b = blockIdx.z, c0 = blockIdx.y * 64, tid = threadIdx.x;
+  const bool second = c0 >= a.C0;                      // C0 % 64 == 0: a slab lies in one source
+  {
+    const float* cs = second ? a.cs1 : a.cs0;
+    const int Cs = second ? a.C1 : a.C0, cc = (second ? c0 - a.C0 : c0) + (tid & 63);
+    double s = 0, q = 0;
+    for (int ch = tid >> 6; ch < nchunk; ch += 4) {
+      const float2 v = *(const float2*)(cs + ((long)(b * nchunk + ch) * Cs + cc) * 2);
+      s += v.x; q += v.y;
+    }
+    red[0][tid >> 6][tid & 63] = s; red[1][tid >> 6][tid & 63] = q;
+  }
+  __syncthreads();
+  if (tid < 64 / cpg) {                                // one thread per group of the slab: cpg x 4 partial sums in a fixed order
+    double s = 0, q = 0;
+    for (int c = 0; c < cpg; ++c)
+      for (int w = 0; w < 4; ++w) { s += red[0][w][tid * cpg + c]; q += red[1][w][tid * cpg + c]; }
+    const double n = (double)HW * cpg, mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0) var = 0;
+    gstat[0][tid] = (float)mean;
+    gstat[1][tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+  __syncthreads();
+  const int v = tid & 7, po = tid >> 3;                // 8 threads x 8 channels per pixel, 32 pixels per iteration
+  const int c = c0 + v * 8;
+  const T* src = second ? (const T*)a.x1 + (long)b * HW * a.C1 + (c - a.C0) : (const T*)a.x0 + (long)b * HW * a.C0 + c;
+  const int ld = second ? a.C1 : a.C0;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int g = (v * 8 + k) / cpg;
+    sc[k] = gstat[1][g] * a.gamma[c + k];
+    sh[k] = a.beta[c + k] - gstat[0][g] * sc[k];
+  }
+  T* out = (T*)a.out + (long)b * HW * C + c;
+  const int p_lo = blockIdx.x * pix_per_block, p_hi = min(HW, p_lo + pix_per_block);
+  auto apply = [&](u4 raw, int p) {
+    union { u4 u; T e[8]; } in, o;
+    in.u = raw;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float y = to_f32(in.e[k]) * sc[k] + sh[k];
+      if (a.silu) y = silu_fast(y);
+      o.e[k] = from_f32<T>(y);
+    }
+    *(u4*)(out + (long)p * C) = o.u;
+  };
+  int p = p_lo + po;
+  for (; p + 96 < p_hi; p += 128) {
+    const u4 r0 = *(const u4*)(src + (long)p * ld), r1 = *(const u4*)(src + (long)(p + 32) * ld);
+    const u4 r2 = *(const u4*)(src + (long)(p + 64) * ld), r3 = *(const u4*)(src + (long)(p + 96) * ld);
+    apply(r0, p); apply(r1, p + 32); apply(r2, p + 64); apply(r3, p + 96);
+  }
+  for (; p < p_hi; p += 32) apply(*(const u4*)(src + (long)p * ld), p);
+}
+
+bool g_gn_apply_cols = true;       // plan switch 27
+bool gn_apply_cols_eligible(const GroupNormApplyArgs& a) {
+  const int C = a.C0 + a.C1, HW = a.H * a.W;
+  if (!g_gn_apply_cols || !a.cs0 || (a.C1 > 0) != (a.cs1 != nullptr) || a.dtype == DT_F32 || !a.x0_lowp || a.down || a.raw_out) return false;
+  if (a.C0 % 64 != 0 || a.C1 % 64 != 0 || C % a.G != 0 || 64 % (C / a.G) != 0) return false;
+  return HW % 64 == 0 && HW <= 4096;
+}
+int launch_gn_apply_cols(const GroupNormApplyArgs& a, hipStream_t s) {
+  T2P_REQUIRE(gn_apply_cols_eligible(a) && a.x0 && a.gamma && a.beta && a.out, "gn_apply_cols arguments");
+  const int C = a.C0 + a.C1, HW = a.H * a.W;
+  // ~1024 blocks per launch; a block's pixel share is a multiple of the 32 pixels of one iteration
+  int parts = std::max(1, 1024 / (a.B * (C / 64)));
+  int ppb = std::max(32, ((HW + parts - 1) / parts + 31) / 32 * 32);
+  dim3 grid((HW + ppb - 1) / ppb, C / 64, a.B);
+  if (a.dtype == DT_BF16) hipLaunchKernelGGL((gn_apply_cols_kernel<bf16_t>), grid, dim3(256), 0, s, a, ppb);
+  else hipLaunchKernelGGL((gn_apply_cols_kernel<f16_t>), grid, dim3(256), 0, s, a, ppb);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
 static inline int ew_grid(long total, int block = 256) {
   long g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));

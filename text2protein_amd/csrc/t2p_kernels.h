@@ -36,9 +36,14 @@ struct GroupNormApplyArgs {
   int x0_lowp = 0;                     // x0 is stored in `dtype` (16-bit) instead of fp32 (single source only)
   void* raw_out = nullptr;             // optional: un-normalised x (concat of both sources) in `dtype`,
                                        // same resolution as the input (not with `down`)
-  float eps = 0.f;                     // launch_gn_small only
+  float eps = 0.f;                     // launch_gn_small / launch_gn_apply_cols only
+  const float* cs0 = nullptr; const float* cs1 = nullptr;   // launch_gn_apply_cols: column statistics of the two sources
 };
 int launch_gn_apply(const GroupNormApplyArgs& a, hipStream_t s);
+// 16-bit maps of <= 4096 pixels whose statistics arrive as per-64-row column sums (GEMM epilogues): finalize and apply in ONE
+// launch -- a block owns a 64-channel slab (whole groups) of one sample, folds the slab's column sums itself, then normalises
+bool gn_apply_cols_eligible(const GroupNormApplyArgs& a);
+int launch_gn_apply_cols(const GroupNormApplyArgs& a, hipStream_t s);
 // statistics + normalisation (+SiLU, + raw copy) of a small map in ONE launch (no `stats` input, no `down`)
 bool gn_small_eligible(const GroupNormApplyArgs& a);
 int launch_gn_small(const GroupNormApplyArgs& a, hipStream_t s);
