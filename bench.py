@@ -60,6 +60,7 @@ def parse():
                     "(include/t2p.h: tile geometry, split-K, individual fusions; all produce correct results)")
     ap.add_argument("--lib", default="", help="A/B measurements: load this libt2p_hip.so (built from another revision)")
     ap.add_argument("--shapes", default="", help="write the profiled steps' GEMM / convolution launches by operand shape (CSV) to this file")
+    ap.add_argument("--layers", default="", help="write the per-block times of one PC step (HIP events at block boundaries, CSV) to this file")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 engine's line (rank 0, N = 1)")
     ap.add_argument("--f32-steps", type=int, default=2)
     return ap.parse_args()
@@ -208,6 +209,14 @@ def main():
             os.makedirs(os.path.dirname(os.path.abspath(args.shapes)), exist_ok=True)
             with open(args.shapes, "w") as f:
                 f.write(f"# {args.workload} {args.dtype} chains={B}: {nprof} profiled PC step(s)\n" + buf.value.decode())
+        if args.layers:           # per-block times of one PC step (tools/layer_table.py)
+            check(lib.t2p_profile_layers_begin())
+            stepper.step(x, x_mean)
+            buf = C.create_string_buffer(1 << 20)
+            check(lib.t2p_profile_layers_end(buf, len(buf)))
+            os.makedirs(os.path.dirname(os.path.abspath(args.layers)), exist_ok=True)
+            with open(args.layers, "w") as f:
+                f.write(f"# {args.workload} {args.dtype} chains={B}: one PC step (2 score evaluations)\n" + buf.value.decode())
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         if conv_n == 0:            # fp32 mode: every convolution runs on the register-staged exact-f32 kernel
             conv_ms, conv_fl, conv_n, c1_ms, c1_fl, c1_n = c1_ms, c1_fl, c1_n, 0.0, 0.0, 0.0

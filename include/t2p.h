@@ -241,6 +241,11 @@ int t2p_profile_attention(double* out3);
  * "kind,M,N,K,taps,batch,launches,ms,flops" (kind as in out9; K "a+b" = a channels per tap + b shortcut columns;
  * taps negative = gathered from the half-resolution map).  T2P_ERR_INVALID when the buffer is too small */
 int t2p_profile_shapes(char* buf, int len);
+/* per-block timing of the score network (UNetModel.forward, ncsnpp.py:220-263): HIP events on the launch stream at every block
+ * boundary between _begin and _end; _end synchronises the device and writes CSV lines
+ * "prefix,kind,map side,in channels,out channels,ms" in launch order (pre = embedding + input convolution, head = out.*) */
+int t2p_profile_layers_begin(void);
+int t2p_profile_layers_end(char* buf, int len);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,10 @@ Differences, all at the edges of the hot path:
     synthetic (``--context synthetic``).
   * ``--decode`` additionally writes ``decoded_<id>.npz`` per sample: the reference's first folding stage
     (sampling_rosetta.py:69-96: mask rounding, crop, clip, inverse scaling) done on the device.
-  * ``--pdb`` conditions need biotite and are broken in the reference: refused.
+  * ``--pdb`` conditions need biotite and are broken in the reference: refused.  Their tensor half is
+    reachable through ``--inpaint_coords <file.pt|synthetic>`` (the featurised chain the reference would have computed from
+    the PDB file): the conditions named in ``config.model.condition`` (length / ss / inpainting with ``--mask_info``) are
+    built from it exactly as ``get_condition_from_batch`` does (utils.py:84-106).  ``--mask_info`` alone is an error.
   * ``checkpoint`` may be the word ``synthetic`` (hash-generated weights, no file needed).
   * extra flags: --dtype (f32|f16|bf16), --seed, --ids, --num_scales / --max_res_num overrides.
 Under ``python -m torch.distributed.run --nproc-per-node N`` (or with ``--gpus N``, which starts the N ranks
@@ -43,7 +46,8 @@ def main():
     parser.add_argument("checkpoint", type=str)
     parser.add_argument("--pdb", type=str, default=None)
     parser.add_argument("--chain", type=str, default="A")
-    parser.add_argument("--mask_info", type=str, default="1:5,10:15")
+    parser.add_argument("--mask_info", type=str, default=None,
+                        help="inpainting residue ranges (reference default '1:5,10:15'); needs --inpaint_coords")
     parser.add_argument("--tag", type=str, default="test")
     parser.add_argument("--device", type=str, default="cuda")
     parser.add_argument("--batch_size", type=int, default=32)
@@ -62,6 +66,10 @@ def main():
     parser.add_argument("--captions", type=str, default=None, help="text file: one caption (or id<TAB>caption) per line")
     parser.add_argument("--tokenizer_path", type=str, default=None)
     parser.add_argument("--embed_table", type=str, default=None)
+    parser.add_argument("--inpaint_coords", type=str, default=None,
+                        help="source of the known 6D maps for the conditions of config.model.condition (what the reference "
+                             "builds from --pdb, utils.py:84-137): a torch file holding {'coords_6d': (B or 1, C, L, L) in "
+                             "[-1, 1], 'lengths': ints or 'aa_str': strings}, or the word 'synthetic' (U(-1, 1) maps, 100 residues)")
     parser.add_argument("--decode", action="store_true", help="also write decoded_<id>.npz (sampling_rosetta.py:69-96)")
     parser.add_argument("--gpus", type=int, default=1, help="start this many ranks (one per GPU) when not under torch.distributed.run")
     parser.add_argument("--global_batch_norm", action="store_true",
@@ -70,7 +78,11 @@ def main():
 
     assert not (args.pdb is not None and args.select_length)
     if args.pdb is not None:
-        raise SystemExit("--pdb conditions are outside the sampling hot path (need biotite; see SURVEY.md section 2, row 10)")
+        raise SystemExit("--pdb conditions are outside the sampling hot path (need biotite; see SURVEY.md section 2, row 10); "
+                         "pass the featurised maps with --inpaint_coords instead")
+    if args.mask_info is not None and args.inpaint_coords is None:
+        raise SystemExit("--mask_info selects residues of KNOWN 6D maps: give their source with --inpaint_coords <file.pt|synthetic>")
+    assert not (args.inpaint_coords is not None and args.select_length)
 
     from text2protein_amd import distributed as D
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:      # before anything touches the GPU
@@ -78,7 +90,7 @@ def main():
         raise SystemExit(D.launch_local(args.gpus, [os.path.abspath(__file__), *sys.argv[1:]]))
     from text2protein_amd import sampling, sde_lib, synth
     from text2protein_amd.checkpoint import restore_checkpoint
-    from text2protein_amd.conditions import get_mask_all_lengths
+    from text2protein_amd.conditions import get_condition_from_batch, get_mask_all_lengths
     from text2protein_amd.config import load_config
     from text2protein_amd.model import HipScoreModel
 
@@ -151,10 +163,34 @@ def main():
     if len(ids) != B:
         raise SystemExit("--ids must list batch_size ids")
 
+    known = None
+    if args.inpaint_coords is not None:
+        # the tensor half of get_conditions_from_pdb (utils.py:119-137): one featurised chain repeated over the batch
+        C_, L_ = config.data.num_channels, config.data.max_res_num
+        if args.inpaint_coords == "synthetic":
+            coords = torch.from_numpy(synth.uniform_pm1(args.seed, "coords_6d", C_ * L_ * L_).reshape(1, C_, L_, L_))
+            known = {"coords_6d": coords, "lengths": [min(100, L_)]}
+        else:
+            known = torch.load(args.inpaint_coords, map_location="cpu", weights_only=True)
+            if "coords_6d" not in known or ("lengths" not in known and "aa_str" not in known):
+                raise SystemExit("--inpaint_coords file must hold 'coords_6d' and 'lengths' (or 'aa_str')")
+        coords = known["coords_6d"].float()
+        if tuple(coords.shape[1:]) != (C_, L_, L_) or coords.shape[0] not in (1, B):
+            raise SystemExit(f"coords_6d must be (1 or {B}, {C_}, {L_}, {L_}), got {tuple(coords.shape)}")
+        rep = B // coords.shape[0]
+        known = {"coords_6d": coords.repeat(rep, 1, 1, 1),
+                 **({"lengths": list(known["lengths"]) * rep} if "lengths" in known else {"aa_str": list(known["aa_str"]) * rep})}
+
+    def to_device(c):
+        return {k: to_device(v) if isinstance(v, dict) else v.to(device) for k, v in c.items()}
+
     for it in range(args.n_iter):
         if args.select_length:
             mask = get_mask_all_lengths(config, batch_size=B)[args.length_index - 1]
             condition = {"length": mask.to(device)}
+        elif known is not None:
+            # sampling_6d.py:146-147 -> get_condition_from_batch (utils.py:84-106): every condition the model was trained with
+            condition = to_device(get_condition_from_batch(config, known, mask_info=args.mask_info or "1:5,10:15"))
         else:
             condition = {}
         sample, n = sampling_fn(score_model, condition=condition, context=context)

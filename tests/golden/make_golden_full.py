@@ -21,6 +21,11 @@ Complements make_golden.py (tiny shapes, per-block taps) with what the benchmark
                          ones, and the score the reference computes after restore_checkpoint + ema.copy_to
                          (sampling_6d.py:64-73).
 
+  run1000_cond_length.npz   the horizon the metric is quoted on: COMPLETE N = 1000 runs of the reference sampler on
+  run1000_test_config.npz   counter-based noise, B = 2: cond_length.yml at L = 128 with the `length` condition
+                         (100 residues: a shard of BASELINE configs[2]) and test_config.yml at L = 64 (no condition);
+                         the final sample only.  `--only run1000_cond_length,run1000_test_config` (15 - 40 min each).
+
 Only data is written; no reference source text goes into the repo.  The GPU box never runs this script.
 """
 import argparse
@@ -128,6 +133,44 @@ def run100_fixture():
                         oracle_rel_l2=np.float64(err))
 
 
+RUN1000 = {   # stem -> (yaml, L, text tokens, noise seed, context seed, length condition or None)
+    "cond_length": ("cond_length.yml", 128, 64, 31337, 21, 100),
+    "test_config": ("test_config.yml", 64, 64, 31338, 22, None),
+}
+
+
+def run1000_fixture(stem):
+    """N = 1000 (2000 score evaluations, 2001 draws), B = 2: the reference's pc_sampler, sampling.py:245-289."""
+    fname, L, T, seed, cseed, length = RUN1000[stem]
+    B, N = 2, 1000
+    cfg = ref_config(fname, L, N)
+    model, _ = reference_model(cfg, 0)
+    C = cfg.data.num_channels
+    shape = (B, C, L, L)
+    ctx = synth.synth_context(B, T, cfg.model.context_dim, cseed)
+    cond = {}
+    if length is not None:
+        m = torch.zeros(B, L, L).bool()
+        m[:, :length, :length] = True
+        cond["length"] = m
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=N)
+    fn = sampling.get_sampling_fn(cfg, sde, shape, 1e-5)
+    noise = CounterNoise(seed)
+    real = torch.randn, torch.randn_like
+    t0 = time.time()
+    torch.randn, torch.randn_like = noise.randn, noise.randn_like
+    try:
+        ref, nfe = fn(model, condition=cond, context=ctx)
+    finally:
+        torch.randn, torch.randn_like = real
+    assert noise.k == 1 + 2 * N and nfe == 2 * N and torch.isfinite(ref).all(), (noise.k, nfe)
+    print(f"[run1000_{stem}] reference run {time.time() - t0:.0f} s, draws = {noise.k}, |sample| rms = "
+          f"{float(ref.pow(2).mean().sqrt()):.4g}", flush=True)
+    np.savez_compressed(os.path.join(HERE, f"run1000_{stem}.npz"), sample=ref.numpy(), nfe=np.int64(nfe),
+                        noise_seed=np.int64(seed), B=np.int64(B), L=np.int64(L), N=np.int64(N), T=np.int64(T),
+                        context_seed=np.int64(cseed), length=np.int64(-1 if length is None else length))
+
+
 def ss_fixture():
     cfg = ss_config()
     seed, B, T = 2, 2, 3
@@ -208,9 +251,10 @@ def checkpoint_fixture():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
+    ap.add_argument("--threads", type=int, default=8)
     a = ap.parse_args()
     only = set(filter(None, a.only.split(",")))
-    torch.set_num_threads(8)
+    torch.set_num_threads(a.threads)
     want = lambda n: not only or n in only   # noqa: E731
     tpath = os.path.join(HERE, "param_tables.json")
     tables = json.load(open(tpath)) if os.path.exists(tpath) else {}
@@ -224,6 +268,9 @@ def main():
         checkpoint_fixture()
     if want("run100"):
         run100_fixture()
+    for stem in RUN1000:          # long: only on request
+        if "run1000_" + stem in only:
+            run1000_fixture(stem)
 
 
 if __name__ == "__main__":

@@ -109,3 +109,36 @@ def test_bench_and_cli_use_the_distributed_module():
         for name in ("D.launch_local(", "D.init_process_group(", "D.gather_samples(", "D.env_rank_world("):
             assert name in src, (f, name)
         assert "dist.init_process_group(" not in src and "dist.all_gather(" not in src
+
+
+@pytest.mark.timeout(60)
+def test_launch_local_stops_the_other_ranks_when_one_fails(tmp_path):
+    """One rank exits 3 while the other sits in a barrier that can never complete: the launcher must return that code within
+    seconds and leave no rank behind (it used to wait for the blocked rank's own collective timeout)."""
+    import time
+    from text2protein_amd import distributed as D
+    pidfile = tmp_path / "blocked.pid"
+    body = ("import os, sys, time\n"
+            "if os.environ['RANK'] == '1':\n"
+            "    time.sleep(0.5); sys.exit(3)\n"
+            f"open({str(pidfile)!r}, 'w').write(str(os.getpid()))\n"
+            "import torch.distributed as dist\n"
+            "dist.init_process_group('gloo', rank=0, world_size=2)\n"      # the peer never joins: blocks here
+            "dist.barrier()\n")
+    t0 = time.monotonic()
+    rc = D.launch_local(2, ["-c", body])
+    assert rc == 3 and time.monotonic() - t0 < 30
+    pid = int(pidfile.read_text())
+    with pytest.raises(ProcessLookupError):
+        os.kill(pid, 0)                                     # the blocked rank was reaped
+
+
+@pytest.mark.timeout(60)
+def test_launch_local_deadline_covers_the_whole_job():
+    import subprocess
+    import time
+    from text2protein_amd import distributed as D
+    t0 = time.monotonic()
+    with pytest.raises(subprocess.TimeoutExpired):
+        D.launch_local(2, ["-c", "import time; time.sleep(60)"], timeout=1.5)
+    assert time.monotonic() - t0 < 15

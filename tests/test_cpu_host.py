@@ -191,3 +191,108 @@ gemm.hip:3:1: remark: Function Name: _ZN3t2p11gemm_kernelIfEEv [-Rpass-analysis=
 gemm.hip:3:1: remark:     ScratchSize [bytes/lane]: 16 [-Rpass-analysis=kernel-resource-usage]"""
     assert scratch_users(remarks) == [("_ZN3t2p15gemm_dma_kernelIaEEv", 544), ("_ZN3t2p11gemm_kernelIfEEv", 16)]
     assert scratch_users(remarks, "gemm_dma_kernel") == [("_ZN3t2p15gemm_dma_kernelIaEEv", 544)]
+
+
+def test_oracle_stands_on_its_own_topology():
+    """The oracle derives the module sequence from the config itself (no import of the product package) and agrees with the
+    product's arch table -- and so, through param_tables.json, with the reference's named_parameters() -- on every shipped YAML."""
+    import re
+    from oracle import t2p_oracle as O
+    from text2protein_amd.arch import build_arch
+    from text2protein_amd.config import load_config
+    src = open(O.__file__).read()
+    assert not re.search(r"^\s*(from|import)\s+text2protein_amd", src, re.M)
+    for y, L in (("test_config.yml", 128), ("cond_length.yml", 128), ("cond_length_inpainting.yml", 128), ("test_config_large.yml", 256)):
+        cfg = load_config(os.path.join(ROOT, "configs", y), **{"data.max_res_num": L})
+        a = build_arch(cfg)
+        mine = [[(l.kind, l.prefix, l.up, l.down) for l in st.layers] for st in a.input_stages + [a.mid_stage] + a.out_stages]
+        ins, mid, outs = O.unet_plan(cfg)
+        assert ins + [mid] + outs == mine
+
+
+def test_condition_builders_match_the_loop_form():
+    """get_mask_all_lengths / selected_mask_batch / get_condition_from_batch against the statement-by-statement form of
+    reference utils.py:62-106,139-148 written out here."""
+    import numpy as np
+    import torch
+    from text2protein_amd import conditions as Cn
+    from text2protein_amd.config import tiny_config
+    cfg = tiny_config(**{"data.min_res_num": 3, "data.max_res_num": 12, "model.condition": ["length", "inpainting"], "data.num_channels": 8})
+    got = Cn.get_mask_all_lengths(cfg, batch_size=3)
+    lengths = np.arange(3, 13)
+    want = torch.zeros(len(lengths), 3, 12, 12).bool()
+    for i, l in enumerate(lengths):
+        want[i, :, :l, :l] = True
+    assert got.dtype == torch.bool and torch.equal(got, want)
+    for info in ("1:5,10:11", "0", "2,4:4,7:20", "3:-2"):
+        m = torch.zeros(2, 12)
+        for r in info.split(","):
+            if ":" in r:
+                a, b = r.split(":")
+                m[:, int(a):int(b) + 1] = 1
+            else:
+                m[:, int(r)] = 1
+        assert torch.equal(Cn.parse_mask_info(info, 2, 12), m)
+        pair = torch.logical_or(m.unsqueeze(-1), m.unsqueeze(1)).bool()
+        batch = Cn.selected_mask_batch({"coords_6d": torch.zeros(2, 8, 12, 12)}, info, cfg)
+        assert torch.equal(batch["mask_inpaint"], pair)
+    coords = torch.rand(2, 8, 12, 12) * 2 - 1
+    c = Cn.get_condition_from_batch(cfg, {"coords_6d": coords, "aa_str": ["ACDEF_______", "ACDEFGHIK___"]}, mask_info="1:2,5")
+    assert list(c) == ["length", "inpainting"]
+    assert c["length"][0, :5, :5].all() and c["length"][0].sum() == 25 and c["length"][1].sum() == 81
+    assert torch.equal(c["inpainting"]["coords_6d"], coords) and c["inpainting"]["mask_inpaint"][0, 1].all()
+    assert not c["inpainting"]["mask_inpaint"][0, 0, 0]
+    c2 = Cn.get_condition_from_batch(cfg, {"coords_6d": coords, "lengths": [5, 9]}, mask_info="1:2,5")
+    assert torch.equal(c2["length"], c["length"])
+    import pytest
+    with pytest.raises(ValueError):
+        Cn.get_condition_from_batch(cfg, {"coords_6d": coords, "lengths": [5, 9]})
+    cfg_ss = tiny_config(**{"data.num_channels": 8, "model.condition": ["length", "ss"]})
+    Lss = cfg_ss.data.max_res_num
+    cs = torch.rand(1, 8, Lss, Lss)
+    assert torch.equal(Cn.get_condition_from_batch(cfg_ss, {"coords_6d": cs, "lengths": [4]})["ss"], cs[:, 4:7])
+
+
+def test_registries_raise_like_the_reference():
+    """Duplicate name -> ValueError, unknown name -> KeyError (reference sampling.py:32-75); both decorator spellings."""
+    import pytest
+    from text2protein_amd import sampling as S
+    assert S.get_predictor("reverse_diffusion") is S.ReverseDiffusionPredictor
+    assert S.get_corrector("langevin") is S.LangevinCorrector
+    with pytest.raises(KeyError):
+        S.get_predictor("nope")
+    with pytest.raises(KeyError):
+        S.get_corrector("nope")
+    with pytest.raises(ValueError, match="Already registered"):
+        S.register_predictor(name="reverse_diffusion")(S.ReverseDiffusionPredictor)
+
+    @S.register_corrector
+    class _PlainNameCorrector(S.Corrector):
+        def update_fn(self, x, t, context=None):
+            return x, x
+    try:
+        assert S.get_corrector("_PlainNameCorrector") is _PlainNameCorrector
+        with pytest.raises(ValueError):
+            S.register_corrector(_PlainNameCorrector)
+        with pytest.raises(TypeError):
+            S.Predictor(None, None)                      # abstract
+    finally:
+        del S._CORRECTORS["_PlainNameCorrector"]
+
+
+def test_checkpoint_loads_without_arbitrary_unpickling():
+    """A reference-written checkpoint (tests/golden/tiny_checkpoint.pth) is plain tensors / containers: weights_only=True."""
+    import torch
+    from text2protein_amd import checkpoint as K
+    src = open(K.__file__).read()
+    assert "weights_only=True" in src and "weights_only=False" not in src
+    d = torch.load(os.path.join(ROOT, "tests", "golden", "tiny_checkpoint.pth"), map_location="cpu", weights_only=True)
+    assert set(d) == {"optimizer", "model", "ema", "step"} and len(d["ema"]["shadow_params"]) > 0
+
+
+def test_cli_refuses_mask_info_without_a_source(tmp_path):
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "sampling_6d.py"), os.path.join(ROOT, "configs", "cond_length_inpainting.yml"),
+                        "synthetic", "--mask_info", "1:5"], capture_output=True, text=True)
+    assert r.returncode != 0 and "--inpaint_coords" in (r.stderr + r.stdout)

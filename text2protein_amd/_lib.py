@@ -88,6 +88,8 @@ SIGNATURES = {
     "t2p_profile_dominant": (_i, [C.POINTER(C.c_double), C.c_char_p, C.c_int]),
     "t2p_profile_attention": (_i, [C.POINTER(C.c_double)]),
     "t2p_profile_shapes": (_i, [C.c_char_p, C.c_int]),
+    "t2p_profile_layers_begin": (_i, []),
+    "t2p_profile_layers_end": (_i, [C.c_char_p, C.c_int]),
     "t2p_op_convert": (_i, [_vp, _vp, _i, _i64, _vp]),
 }
 

@@ -40,6 +40,16 @@ def source_hash(ablation: bool = False) -> str:
     return h.hexdigest()
 
 
+def unit_hash(src: str, flags) -> str:
+    """Identity of one object file: its source, every header and the flags (unchanged units are not recompiled)."""
+    h = hashlib.sha256()
+    h.update(" ".join(flags).encode())
+    for f in [src] + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _read(path) -> str:
     try:
         with open(path) as f:
@@ -100,6 +110,7 @@ def _build_locked(lib: str, stamp: str, verbose: bool, ablation: bool) -> str:
     hipcc = _hipcc()
     objs = []
     procs = []
+    pending = {}
     flags = FLAGS + (["-DT2P_ABLATION"] if ablation else [])
     if os.path.exists(stamp):
         os.remove(stamp)
@@ -111,10 +122,16 @@ def _build_locked(lib: str, stamp: str, verbose: bool, ablation: bool) -> str:
         cmd = [hipcc, *flags, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if part is not None:
             cmd[1:1] = ["-Rpass-analysis=kernel-resource-usage", f"-DT2P_GEMM_PART={part}"]
+        uh = unit_hash(src, cmd[1:-4])
+        if os.path.exists(obj) and _read(obj + ".hash") == uh:
+            continue
+        if os.path.exists(obj + ".hash"):
+            os.remove(obj + ".hash")
+        pending[obj] = uh
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for src, p in procs:
+        procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, obj, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
@@ -133,6 +150,8 @@ def _build_locked(lib: str, stamp: str, verbose: bool, ablation: bool) -> str:
                     skip = 0
                     keep.append(l)
             out = "\n".join(keep)
+        with open(obj + ".hash", "w") as f:
+            f.write(pending[obj] + "\n")
         if verbose and out.strip():
             print(out)
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs]

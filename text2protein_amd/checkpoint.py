@@ -36,7 +36,8 @@ def ema_state_dict(config, loaded_state):
 
 def restore_checkpoint(ckpt_path, model, config, device="cpu", use_ema=True):
     """Load a reference ``.pth`` into a ``HipScoreModel``; returns the checkpoint's ``step``."""
-    loaded = torch.load(ckpt_path, map_location=device, weights_only=False)
+    # a reference checkpoint holds tensors, lists, dicts and numbers only: no arbitrary unpickling of user-supplied files
+    loaded = torch.load(ckpt_path, map_location=device, weights_only=True)
     if use_ema and "ema" in loaded and loaded["ema"].get("shadow_params"):
         sd = ema_state_dict(config, loaded)
     else:

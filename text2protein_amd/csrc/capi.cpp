@@ -17,7 +17,7 @@ using namespace t2p;
     return T2P_ERR_STATE;                              \
   }
 
-namespace t2p { extern bool g_pre_conv_mfma, g_gn_apply_cols; }
+namespace t2p { extern bool g_pre_conv_mfma, g_gn_apply_cols; void layer_profile_begin(); int layer_profile_end(std::string* out); }
 extern "C" {
 
 const char* t2p_last_error(void) { return get_last_error(); }
@@ -498,6 +498,21 @@ int t2p_profile_shapes(char* buf, int len) {
   API_BEGIN
   T2P_REQUIRE(buf && len > 0, "null argument");
   return profile_shapes(buf, len);
+  API_END
+}
+
+int t2p_profile_layers_begin(void) {
+  t2p::layer_profile_begin();
+  return T2P_OK;
+}
+
+int t2p_profile_layers_end(char* buf, int len) {
+  API_BEGIN
+  T2P_REQUIRE(buf && len > 0, "null argument");
+  std::string out;
+  T2P_TRY(t2p::layer_profile_end(&out));
+  std::snprintf(buf, (size_t)len, "%s", out.c_str());
+  return T2P_OK;
   API_END
 }
 

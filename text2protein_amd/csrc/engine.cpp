@@ -7,7 +7,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <set>
 
@@ -27,13 +29,53 @@ const char* get_last_error() { return g_last_error.c_str(); }
 
 int ensure_dynamic_lds(const void* kernel, int bytes) {
   static std::mutex mu;
-  static std::set<std::pair<const void*, int>> done;     // (kernel, device)
+  static std::map<std::pair<const void*, int>, int> done;     // (kernel, device) -> largest size set so far
   int dev = 0;
   T2P_HIP_CHECK(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lock(mu);
-  if (done.count({kernel, dev})) return T2P_OK;
+  auto it = done.find({kernel, dev});
+  if (it != done.end() && it->second >= bytes) return T2P_OK;
   T2P_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  done.insert({kernel, dev});
+  done[{kernel, dev}] = bytes;
+  return T2P_OK;
+}
+
+// ---- per-layer timing (development / bench: t2p_profile_layers_*): HIP events on the launch stream at block boundaries ----
+struct LayerRec { std::string label; hipEvent_t e0, e1; };
+static bool g_layer_prof = false;
+static std::vector<LayerRec> g_layer_recs;
+void layer_profile_begin() {
+  for (LayerRec& r : g_layer_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  g_layer_recs.clear();
+  g_layer_prof = true;
+}
+struct LayerScope {
+  int idx = -1;
+  hipStream_t s;
+  LayerScope(const std::string& label, hipStream_t st) : s(st) {
+    if (!g_layer_prof) return;
+    LayerRec r; r.label = label;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    (void)hipEventRecord(r.e0, s);
+    idx = (int)g_layer_recs.size();
+    g_layer_recs.push_back(r);
+  }
+  ~LayerScope() { if (idx >= 0) (void)hipEventRecord(g_layer_recs[idx].e1, s); }
+};
+// CSV "label,ms" per record, in launch order
+int layer_profile_end(std::string* out) {
+  g_layer_prof = false;
+  T2P_HIP_CHECK(hipDeviceSynchronize());
+  out->clear();
+  for (LayerRec& r : g_layer_recs) {
+    float ms = 0.f;
+    T2P_HIP_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+    char buf[64];
+    std::snprintf(buf, sizeof buf, ",%.4f\n", ms);
+    *out += r.label + buf;
+    (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+  }
+  g_layer_recs.clear();
   return T2P_OK;
 }
 
@@ -947,6 +989,8 @@ int Engine::run_stage(Stage& st, Act& h, const Act* skip, int B, hipStream_t s) 
   for (size_t i = 0; i < st.layers.size(); ++i) {
     Layer& L = st.layers[i];
     Act nxt;
+    LayerScope scope(L.prefix + (L.kind == 0 ? (L.up ? ",res_up," : L.down ? ",res_down," : ",res,") : L.kind == 1 ? ",attn," : ",st,") +
+                     std::to_string(cur.H) + "," + std::to_string(L.in_ch) + "," + std::to_string(L.out_ch), s);
     if (L.kind == 0) T2P_TRY(res_block(L, cur, i == 0 ? skip : nullptr, &nxt, B, s));
     else if (L.kind == 1) T2P_TRY(attn_block(L, cur, &nxt, B, s));
     else T2P_TRY(st_block(L, cur, &nxt, B, s));
@@ -1002,6 +1046,7 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
   T2P_REQUIRE(x && out && B > 0 && (labels || step_counter), "score arguments");
   const int L = cfg_.max_res_num, HW = L * L, Cx = cfg_.num_channels, N = cfg_.num_scales;
   const int R = labels ? B : 1;
+  std::unique_ptr<LayerScope> pre_scope(new LayerScope("pre,pre," + std::to_string(L) + "," + std::to_string(Cx) + "," + std::to_string(nf_), s));
   POOL_GET(emb, float*, (size_t)R * nf_ * 4);
   POOL_GET(t1, float*, (size_t)R * temb_dim_ * 4);
   POOL_GET(t2, float*, (size_t)R * temb_dim_ * 4);
@@ -1054,6 +1099,7 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
     h0_lowp = true;
   }
   pool_.put(emb); pool_.put(t1); pool_.put(t2);
+  pre_scope.reset();
 
   std::vector<Act> hs;
   Act h{h0, nf_, L, L, h0_stats, h0_lowp};
@@ -1075,6 +1121,7 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
   }
   T2P_REQUIRE(hs.empty(), "skip stack not consumed");
   // head: GroupNorm -> SiLU -> conv3x3 (nf -> C), stored NCHW and divided by sigma[label]
+  LayerScope head_scope("head,head," + std::to_string(L) + "," + std::to_string(final_ch_) + "," + std::to_string(Cx), s);
   void* a = nullptr;
   T2P_TRY(group_norm(h, nullptr, head_norm_, 1e-6f, 1, 0, B, &a, s));
   free_act(h);
@@ -1222,10 +1269,14 @@ int Sampler::step_graph(float* x, float* x_mean, hipStream_t s) {
   if (!graph_exec_) {
     hipGraph_t graph = nullptr;
     T2P_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int step_before = host_step_;
     const int rc = step(x, x_mean, nullptr, nullptr, s);
-    --host_step_;                        // the capture enqueued nothing: the replay below is the step
+    host_step_ = step_before;            // the capture enqueued nothing: the replay below is the step
     const hipError_t ec = hipStreamEndCapture(s, &graph);
-    if (rc != T2P_OK) return rc;
+    if (rc != T2P_OK) {                  // a partial capture is dropped, the mirror of the device counter is untouched
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
     T2P_HIP_CHECK(ec);
     T2P_HIP_CHECK(hipGraphInstantiate(&graph_exec_, graph, nullptr, nullptr, 0));
     (void)hipGraphDestroy(graph);

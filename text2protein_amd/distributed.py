@@ -46,32 +46,63 @@ def free_port() -> int:
     return port
 
 
-def launch_local(n_ranks: int, argv, env_extra=None, timeout=None) -> int:
+def launch_local(n_ranks: int, argv, env_extra=None, timeout=None, poll_s=0.2) -> int:
     """Start ``n_ranks`` fresh child interpreters running ``argv`` (a script path + its arguments), one rank per
     GPU of this node, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way
-    ``torch.distributed.run`` sets them; returns the largest exit code.
+    ``torch.distributed.run`` sets them; returns the exit code of the job: 0 when every rank succeeded, otherwise the
+    code of the FIRST rank seen failing (signals as positive numbers).
+
+    The ranks are watched together: as soon as one exits non-zero the others are terminated (they would otherwise sit in
+    ``init_process_group`` / a barrier / the gather until the collective's own 10-30 minute timeout, holding every GPU).
+    ``timeout`` is a deadline in seconds for the WHOLE job (``subprocess.TimeoutExpired`` after the ranks are killed).
 
     This is what ``python bench.py --gpus N`` does when it is started directly (no WORLD_SIZE in the
     environment).  It must run BEFORE the calling process touches the GPU: the children are new processes (never
     a re-exec of a process that holds a GPU context), and the parent only waits for them."""
+    import time
     port = free_port()
     procs = []
     for r in range(n_ranks):
         env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # ROCm shares device buffers between the ranks of a node (RCCL's intra-node transport, CUDA-tensor IPC) through IPC
+        # handles; hosts whose driver offers only the dmabuf flavour (this pool's: without the variable RCCL start-up fails
+        # with "hipIpcGetMemHandle: invalid argument") need the legacy mode switched off.  The launcher passes the caller's
+        # value through and sets 0 only when the variable is absent; HSA_ENABLE_IPC_MODE_LEGACY=1 in the caller's
+        # environment keeps the legacy mode on hosts that want it.
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.update(env_extra or {})
         procs.append(subprocess.Popen([sys.executable, *argv], env=env))
-    rc = 0
-    try:
+
+    def stop_all():
         for p in procs:
-            rc = max(rc, abs(p.wait(timeout=timeout)))
-    except BaseException:
-        for p in procs:                    # one rank failed or we were interrupted: do not leave the others behind
             if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
                 p.kill()
+                p.wait()
+
+    deadline = None if timeout is None else time.monotonic() + float(timeout)
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            failed = [c for c in codes if c not in (None, 0)]
+            if failed:
+                stop_all()
+                return abs(failed[0])
+            if all(c == 0 for c in codes):
+                return 0
+            if deadline is not None and time.monotonic() > deadline:
+                stop_all()
+                raise subprocess.TimeoutExpired([sys.executable, *argv], timeout)
+            time.sleep(poll_s)
+    except BaseException:
+        stop_all()                           # interrupted: do not leave ranks behind
         raise
-    return rc
 
 
 def barrier(dist=None, device=None):

@@ -30,111 +30,95 @@ from . import _lib, sde_lib
 from ._lib import SamplerConfig, T2PError, check, ptr, stream_ptr
 from .model import HipScoreModel
 
-_CORRECTORS = {}
-_PREDICTORS = {}
+class _Registry(dict):
+    """name -> class table behind ``register_predictor`` / ``register_corrector`` (reference sampling.py:28-75):
+    registering a taken name raises ``ValueError``, looking up an unknown one raises ``KeyError``."""
+
+    def __init__(self, what):
+        super().__init__()
+        self.what = what
+
+    def decorator(self, cls=None, *, name=None):
+        """``@reg`` or ``@reg(name=...)``; the class is returned unchanged."""
+        def add(c):
+            key = name or c.__name__
+            if key in self:
+                raise ValueError(f"Already registered model with name: {key}")
+            self[key] = c
+            return c
+        return add(cls) if cls is not None else add
 
 
-def register_predictor(cls=None, *, name=None):
-    """A decorator for registering predictor classes."""
-
-    def _register(cls):
-        local_name = cls.__name__ if name is None else name
-        if local_name in _PREDICTORS:
-            raise ValueError(f"Already registered model with name: {local_name}")
-        _PREDICTORS[local_name] = cls
-        return cls
-
-    return _register if cls is None else _register(cls)
-
-
-def register_corrector(cls=None, *, name=None):
-    """A decorator for registering corrector classes."""
-
-    def _register(cls):
-        local_name = cls.__name__ if name is None else name
-        if local_name in _CORRECTORS:
-            raise ValueError(f"Already registered model with name: {local_name}")
-        _CORRECTORS[local_name] = cls
-        return cls
-
-    return _register if cls is None else _register(cls)
-
-
-def get_predictor(name):
-    return _PREDICTORS[name]
-
-
-def get_corrector(name):
-    return _CORRECTORS[name]
+_PREDICTORS, _CORRECTORS = _Registry("predictor"), _Registry("corrector")
+register_predictor, register_corrector = _PREDICTORS.decorator, _CORRECTORS.decorator
+get_predictor, get_corrector = _PREDICTORS.__getitem__, _CORRECTORS.__getitem__
 
 
 # ------------------------------------------------------------------------------------------------
 # score function adapter
 # ------------------------------------------------------------------------------------------------
 def get_score_fn(sde, model, train=False, continuous=False):
-    """models/utils.py:126-176.  ``model`` is a ``HipScoreModel`` (or any callable with the
-    reference signature ``model(x, labels, context)``)."""
+    """models/utils.py:126-176: ``score_fn(x, t, context=None)`` for ``model(x, labels, context)`` (a ``HipScoreModel`` or
+    any callable with the reference signature).  VE: integer labels ``round((T - t)(N - 1))`` (noisiest level first) or,
+    ``continuous``, the marginal std; the network output is the score.  VP / subVP: fractional labels ``t (N - 1)``
+    (``t * 999`` when continuous or subVP) and the output is divided by minus the marginal std."""
     if train:
         raise T2PError("the HIP engine is inference-only (train=True is not on the sampling path)")
+    ve = isinstance(sde, sde_lib.VESDE)
+    sub = isinstance(sde, sde_lib.subVPSDE)
+    if not (ve or sub or isinstance(sde, sde_lib.VPSDE)):
+        raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
 
-    def model_fn(x, labels, context=None):
+    def evaluate(x, labels, context):
         model.eval()
         return model(x, labels, context)
 
-    if isinstance(sde, (sde_lib.VPSDE, sde_lib.subVPSDE)):
-        def score_fn(x, t, context=None):
-            if continuous or isinstance(sde, sde_lib.subVPSDE):
-                labels = t * 999
-                score = model_fn(x, labels, context)
-                std = sde.marginal_prob_std(t)
-            else:
-                labels = t * (sde.N - 1)
-                score = model_fn(x, labels, context)
-                std = sde.sqrt_1m_alphas_cumprod.to(labels.device)[labels.long()]
-            return -score / std[:, None, None, None].to(score.device)
-    elif isinstance(sde, sde_lib.VESDE):
-        def score_fn(x, t, context=None):
-            if continuous:
-                labels = sde.marginal_prob_std(t)
-            else:
-                # For VE-trained models, t=0 corresponds to the highest noise level
-                labels = torch.round((sde.T - t) * (sde.N - 1)).long()
-            return model_fn(x, labels, context)
-    else:
-        raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
-    return score_fn
+    def score_ve(x, t, context=None):
+        labels = sde.marginal_prob_std(t) if continuous else torch.round((sde.T - t) * (sde.N - 1)).long()
+        return evaluate(x, labels, context)
+
+    def score_vp(x, t, context=None):
+        if continuous or sub:
+            out = evaluate(x, t * 999, context)
+            std = sde.marginal_prob_std(t)
+        else:
+            labels = t * (sde.N - 1)
+            out = evaluate(x, labels, context)
+            std = sde.sqrt_1m_alphas_cumprod.to(labels.device)[labels.long()]
+        return -out / std[:, None, None, None].to(out.device)
+
+    return score_ve if ve else score_vp
 
 
 # ------------------------------------------------------------------------------------------------
 # predictors / correctors
 # ------------------------------------------------------------------------------------------------
-class Predictor(abc.ABC):
-    """The abstract class for a predictor algorithm."""
+class _UpdateRule(abc.ABC):
+    """Common part of ``Predictor`` and ``Corrector`` (sampling.py:107-150): holds the SDE and the score function;
+    ``update_fn(x, t, context=None) -> (x, x_mean)`` is the one method a registered class supplies."""
+
+    def __init__(self, sde, score_fn):
+        self.sde, self.score_fn = sde, score_fn
+
+    @abc.abstractmethod
+    def update_fn(self, x, t, context=None):
+        ...
+
+
+class Predictor(_UpdateRule):
+    """Predictor algorithm: ``Predictor(sde, score_fn, probability_flow=False)``."""
 
     def __init__(self, sde, score_fn, probability_flow=False):
-        super().__init__()
-        self.sde = sde
-        self.score_fn = score_fn
+        super().__init__(sde, score_fn)
         self.probability_flow = probability_flow
 
-    @abc.abstractmethod
-    def update_fn(self, x, t, context=None):
-        """One update of the predictor -> (x, x_mean)."""
 
-
-class Corrector(abc.ABC):
-    """The abstract class for a corrector algorithm."""
+class Corrector(_UpdateRule):
+    """Corrector algorithm: ``Corrector(sde, score_fn, snr, n_steps)``."""
 
     def __init__(self, sde, score_fn, snr, n_steps):
-        super().__init__()
-        self.sde = sde
-        self.score_fn = score_fn
-        self.snr = snr
-        self.n_steps = n_steps
-
-    @abc.abstractmethod
-    def update_fn(self, x, t, context=None):
-        """One update of the corrector -> (x, x_mean)."""
+        super().__init__(sde, score_fn)
+        self.snr, self.n_steps = snr, n_steps
 
 
 def _device_randn_like(x, seed, stream_id):
@@ -294,17 +278,17 @@ class PCStepper:
         self.N = int(sde.N)
         if all_reduce is not None:
             self._sums = torch.zeros(2, device=model.device, dtype=torch.float32)
+            self._cb_error = err = []               # the trampoline's closure holds this list, not the stepper (no cycle)
 
-            def _cb(_ptr, _stream, _user, _t=self._sums, _fn=all_reduce):
+            def _cb(_ptr, _stream, _user, _t=self._sums, _fn=all_reduce, _err=err):
                 try:
                     _fn(_t)                        # sums the caller-owned buffer the sampler just filled
                     return 0
                 except Exception as e:  # noqa: BLE001  (must not unwind through the C frame)
-                    self._cb_error = e
+                    _err.append(e)
                     return 1
 
             self._cb = _lib.ALLREDUCE_FN(_cb)       # keep the trampoline alive as long as the sampler
-            self._cb_error = None
             check(self.lib.t2p_sampler_set_norm_allreduce(self._h, ptr(self._sums), self._cb, None))
 
     def set_seed(self, seed):
@@ -318,8 +302,16 @@ class PCStepper:
         check(self.lib.t2p_sampler_reset(self._h, int(step), stream_ptr()))
 
     def step(self, x, x_mean, noise_corrector=None, noise_predictor=None):
-        check(self.lib.t2p_sampler_step(self._h, ptr(x), ptr(x_mean), ptr(noise_corrector), ptr(noise_predictor),
-                                        stream_ptr()))
+        try:
+            check(self.lib.t2p_sampler_step(self._h, ptr(x), ptr(x_mean), ptr(noise_corrector), ptr(noise_predictor),
+                                            stream_ptr()))
+        except T2PError as e:
+            pending = getattr(self, "_cb_error", None)
+            if pending:                                # the all-reduce callable raised: surface ITS error
+                cause = pending.pop()
+                pending.clear()
+                raise T2PError(f"the norm all-reduce failed: {cause!r}") from cause
+            raise e
 
     def step_graph(self, x, x_mean):
         """One PC step replayed from a captured hipGraph (device noise; needs a non-default stream)."""
