@@ -62,30 +62,180 @@ def parse():
     ap.add_argument("--shapes", default="", help="write the profiled steps' GEMM / convolution launches by operand shape (CSV) to this file")
     ap.add_argument("--layers", default="", help="write the per-block times of one PC step (HIP events at block boundaries, CSV) to this file")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 engine's line (rank 0, N = 1)")
-    ap.add_argument("--f32-steps", type=int, default=2)
+    ap.add_argument("--f32-steps", type=int, default=10)
+    ap.add_argument("--no-cfg3", action="store_true", help="with --gpus N > 1: skip the additional cfg3 (BASELINE configs[2]) measurement")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sd, ctx_cpu, n_scales):
-    """The oracle (CPU restatement of the reference, checked against the reference's own runs)
-    timed on this box's host cores on a bounded sample of the same workload: 2 chains, 1 warm-up
-    score evaluation, then 1 PC step (2 evaluations); scaled by N PC steps per sample."""
+def cpu_baseline(cfg, sd, ctx_cpu, n_scales, k_steps=3):
+    """The oracle (CPU restatement of the reference, checked against the reference's own runs) timed on this box's host
+    cores on a bounded sample of the same workload: 2 chains, one warm-up PC step (thread pools,
+    allocator, caches), then k = 3 PC steps (6 score evaluations) timed; scaled by N PC steps per sample -- every step
+    has the same shapes and cost."""
     from oracle import t2p_oracle as O
     B = 2
     C_, L = cfg.data.num_channels, cfg.data.max_res_num
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(B, C_, L, L, generator=g) * cfg.model.sigma_max
-    t = torch.ones(B)
+    draw = lambda s: torch.randn(*s, generator=g)   # noqa: E731
     with torch.no_grad():
-        O.score_fn_ve(sd, cfg, x, t, ctx_cpu[:B])          # warm-up (thread pools, allocator)
+        O.pc_sampler_ve(sd, cfg, (B, C_, L, L), ctx_cpu[:B], noise_fn=draw, n_steps_limit=1)          # warm-up step
         t0 = time.perf_counter()
-        O.pc_sampler_ve(sd, cfg, (B, C_, L, L), ctx_cpu[:B], noise_fn=lambda s: torch.randn(*s, generator=g),
-                        n_steps_limit=1)
+        O.pc_sampler_ve(sd, cfg, (B, C_, L, L), ctx_cpu[:B], noise_fn=draw, n_steps_limit=k_steps)
         dt = time.perf_counter() - t0
-    return {"value": B / (dt * n_scales), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{B} chains x 1 PC step (2 score evaluations) of the same workload on the host CPU "
-                      f"({os.cpu_count()} logical cores visible), scaled by {n_scales} PC steps per sample; "
-                      f"{dt:.2f} s measured"}
+    return {"value": B / (dt / k_steps * n_scales), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{B} chains x {k_steps} PC steps ({2 * k_steps} score evaluations) of the same workload after one warm-up "
+                      f"step, on the host CPU with {torch.get_num_threads()} torch intra-op threads ({os.cpu_count()} logical cores "
+                      f"visible), scaled by {n_scales} PC steps per sample; {dt:.2f} s measured"}
+
+
+class Job:
+    """One workload on this rank's GPU: model, text K/V, fused stepper, state."""
+
+    def __init__(self, name, dtype, dev, rank, batch=None):
+        from text2protein_amd import distributed as D
+        from text2protein_amd import sampling, sde_lib, synth
+        from text2protein_amd.config import load_config
+        from text2protein_amd.model import HipScoreModel
+        fname, overrides, chains, T, cond_kind = WORKLOADS[name]
+        self.name, self.fname, self.dtype, self.dev, self.T, self.cond_kind = name, fname, dtype, dev, T, cond_kind
+        self.B = B = batch or chains
+        self.cfg = cfg = load_config(os.path.join(ROOT, "configs", fname), **overrides)
+        cfg.device = str(dev)
+        self.N = cfg.model.num_scales
+        self.C, self.L = cfg.data.num_channels, cfg.data.max_res_num
+        t0 = time.perf_counter()
+        self.sd = synth.synth_state_dict(cfg, seed=0)                 # same weights on every rank (replicated model)
+        self.model = HipScoreModel(cfg, dtype=dtype, device=str(dev))
+        self.model.load_state_dict(self.sd)
+        self.ctx_cpu = synth.synth_context(B, T, cfg.model.context_dim, seed=1000 + rank)
+        self.ctx = self.ctx_cpu.to(dev)
+        self.model.set_context(self.ctx)                              # one-off K/V projection of the frozen text
+        self.sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=self.N)
+        self.stepper = self.new_stepper(self.model, rank)
+        self.x = sampling._device_randn_like(torch.empty(B, self.C, self.L, self.L, device=dev), D.rank_seed(12345, rank), 0) * self.sde.prior_scale()
+        self.cond = None
+        if cond_kind:
+            from text2protein_amd.conditions import synthetic_condition
+            x, mask = sampling.apply_conditions(self.x, synthetic_condition(cfg, B, cond_kind, dev))
+            self.x = x.float().contiguous()
+            self.cond = (mask.to(torch.uint8).contiguous(), self.x.clone())
+            self.stepper.set_condition(*self.cond)
+        self.x_mean = torch.empty_like(self.x)
+        self.stepper.reset(0)
+        torch.cuda.synchronize()
+        self.setup_s = time.perf_counter() - t0
+
+    def new_stepper(self, model, rank):
+        from text2protein_amd import distributed as D
+        from text2protein_amd import sampling
+        c = self.cfg.sampling
+        return sampling.PCStepper(model, self.sde, self.B, c.snr, c.n_steps_each, c.probability_flow, c.noise_removal, 1e-5,
+                                  seed=D.rank_seed(0, rank))
+
+    def timed(self, steps, warmup, dist, graph=0):
+        """W untimed steps, then exactly `steps` PC steps between barrier + device synchronisation on both sides; the
+        slowest rank's time; the single all_gather of a run is inside the region."""
+        from text2protein_amd import distributed as D
+        st, x, xm, dev = self.stepper, self.x, self.x_mean, self.dev
+        side = torch.cuda.Stream(device=dev) if graph else None           # stream capture needs a real stream
+        run_step = st.step
+        if graph:
+            def run_step(a, b):
+                with torch.cuda.stream(side):
+                    st.step_graph(a, b)
+            torch.cuda.synchronize()
+            for _ in range(2):                                            # eager step + capture
+                run_step(x, xm)
+            torch.cuda.synchronize()
+
+        def rewind():
+            # the device-side step counter is written on the current stream: nothing of the side stream may be in flight
+            if side is not None:
+                side.synchronize()
+            st.reset(0)
+
+        for _ in range(warmup):
+            run_step(x, xm)
+        if dist is not None:
+            D.gather_samples(xm, dist)                       # RCCL communicator set-up is not part of a run
+        # the schedule tables hold N steps: the timed region starts at step 0 of a run and rewinds every N steps
+        rewind()
+        D.barrier(dist, dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if i and i % self.N == 0:
+                rewind()
+            run_step(x, xm)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        gathered = D.gather_samples(xm, dist)                # the single collective of a run (no-op at N = 1)
+        D.barrier(dist, dev)
+        dt = D.max_over_ranks(time.perf_counter() - t0, dist, dev)
+        world = dist.get_world_size() if dist is not None else 1
+        finite = bool(torch.isfinite(gathered).all().item()) and gathered.shape[0] == self.B * world
+        return dt, finite
+
+    def describe(self):
+        return (f"{self.name}: {self.fname} L={self.L} N={self.N} chains/GPU={self.B} C={self.C} text_tokens={self.T} "
+                f"condition={self.cond_kind or 'none'}; step = 1 PC step (2 score evals + SDE updates); sample = {self.N} PC steps")
+
+
+def kernel_roofline(job, stepper, lib, peak, shapes="", layers=""):
+    """Every GEMM / convolution launch of ONE PC step timed with HIP events on the launch stream (t2p_profile_*): the dominant
+    3x3-convolution instantiation against the dense MFMA peak of the dtype, plus the other kernel classes."""
+    from text2protein_amd._lib import check
+    x, x_mean = job.x, job.x_mean
+    stepper.reset(0)
+    check(lib.t2p_profile_begin())
+    stepper.step(x, x_mean)
+    o = (C.c_double * 9)()
+    check(lib.t2p_profile_end(o))
+    conv_ms, conv_fl, conv_n, g_ms, g_fl, g_n, c1_ms, c1_fl, c1_n = list(o)
+    dom, dom_name = (C.c_double * 4)(), C.create_string_buffer(256)
+    check(lib.t2p_profile_dominant(dom, dom_name, 256))
+    dom_ms, dom_fl, dom_n, dom_bytes = list(dom)
+    att = (C.c_double * 3)()
+    check(lib.t2p_profile_attention(att))
+    att_ms, att_fl, att_n = list(att)
+    if shapes:           # the GEMM / convolution launches of the profiled step by operand shape (tools/shapes_table.py)
+        buf = C.create_string_buffer(1 << 20)
+        check(lib.t2p_profile_shapes(buf, len(buf)))
+        os.makedirs(os.path.dirname(os.path.abspath(shapes)), exist_ok=True)
+        with open(shapes, "w") as f:
+            f.write(f"# {job.name} {job.dtype} chains={job.B}: 1 profiled PC step(s)\n" + buf.value.decode())
+    if layers:           # per-block times of one PC step (tools/layer_table.py)
+        check(lib.t2p_profile_layers_begin())
+        stepper.step(x, x_mean)
+        buf = C.create_string_buffer(1 << 20)
+        check(lib.t2p_profile_layers_end(buf, len(buf)))
+        os.makedirs(os.path.dirname(os.path.abspath(layers)), exist_ok=True)
+        with open(layers, "w") as f:
+            f.write(f"# {job.name} {job.dtype} chains={job.B}: one PC step (2 score evaluations)\n" + buf.value.decode())
+    tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0   # noqa: E731
+    if conv_n == 0:            # fp32 mode: every convolution runs on the register-staged exact-f32 kernel
+        conv_ms, conv_fl, conv_n, c1_ms, c1_fl, c1_n = c1_ms, c1_fl, c1_n, 0.0, 0.0, 0.0
+        kname = "gemm_kernel<float, ...> (register-staged implicit-GEMM 3x3 convolution, v_mfma_f32_32x32x2_f32)"
+    else:
+        kname = "gemm_dma_kernel (LDS-DMA implicit-GEMM 3x3 convolution)"
+    all_conv = {"achieved": tf(conv_fl, conv_ms), "launches_per_step": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
+                "share_of_step_ms": conv_ms}
+    if dom_n > 0:
+        # the dominant instantiation by name: its average launch duration is the figure to hold against the rocprofv3
+        # --stats average of the same kernel in profiles/<round>_kernel_stats.csv
+        kname = dom_name.value.decode()
+        conv_ms, conv_fl, conv_n = dom_ms, dom_fl, dom_n
+    ach = tf(conv_fl, conv_ms)
+    return {
+        "bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+        "launches_per_step": conv_n, "avg_launch_ms": conv_ms / max(conv_n, 1),
+        "algorithmic_gflop_per_launch": conv_fl / max(conv_n, 1) / 1e9,
+        "algorithmic_bytes_per_launch": (dom_bytes / dom_n) if dom_n > 0 else None,
+        "share_of_step_ms": conv_ms, "all_conv3x3_launches": all_conv,
+        "other_gemm": {"achieved": tf(g_fl, g_ms), "launches_per_step": g_n, "share_of_step_ms": g_ms, "frac": tf(g_fl, g_ms) / peak},
+        "conv_on_v1_kernel": {"launches_per_step": c1_n, "share_of_step_ms": c1_ms},
+        # fused self / text cross-attention (attn_flash_kernel): the "attention roofline" of the north star
+        "attention": {"achieved": tf(att_fl, att_ms), "launches_per_step": att_n, "share_of_step_ms": att_ms, "frac": tf(att_fl, att_ms) / peak},
+    }
 
 
 def main():
@@ -102,183 +252,85 @@ def main():
     dev = torch.device("cuda", dev_index)
     dist = D.init_process_group(dev)                         # "nccl" = RCCL over xGMI on ROCm; None at N = 1
 
-    from text2protein_amd import sampling, sde_lib, synth
-    from text2protein_amd._lib import check, load, set_plan_switches
-    from text2protein_amd.config import load_config
+    from text2protein_amd._lib import load, set_plan_switches
     from text2protein_amd.model import HipScoreModel
-
-    fname, overrides, chains, T, cond_kind = WORKLOADS[args.workload]
-    B = args.batch or chains
-    cfg = load_config(os.path.join(ROOT, "configs", fname), **overrides)
-    cfg.device = str(dev)
-    N = cfg.model.num_scales
-    C_, L = cfg.data.num_channels, cfg.data.max_res_num
-
     if args.lib:
         from text2protein_amd import _lib as _L
         _L.load_path(args.lib)
     set_plan_switches(args.plan)
-    t_setup = time.perf_counter()
-    sd = synth.synth_state_dict(cfg, seed=0)                 # same weights on every rank (replicated model)
-    model = HipScoreModel(cfg, dtype=args.dtype, device=str(dev))
-    model.load_state_dict(sd)
-    ctx_cpu = synth.synth_context(B, T, cfg.model.context_dim, seed=1000 + rank)
-    ctx = ctx_cpu.to(dev)
-    model.set_context(ctx)                                   # one-off K/V projection of the frozen text
-    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=N)
-    stepper = sampling.PCStepper(model, sde, B, cfg.sampling.snr, cfg.sampling.n_steps_each,
-                                 cfg.sampling.probability_flow, cfg.sampling.noise_removal, 1e-5, seed=D.rank_seed(0, rank))
-    x = sampling._device_randn_like(torch.empty(B, C_, L, L, device=dev), D.rank_seed(12345, rank), 0) * sde.prior_scale()
-    if cond_kind:
-        from text2protein_amd.conditions import synthetic_condition
-        x, mask = sampling.apply_conditions(x, synthetic_condition(cfg, B, cond_kind, dev))
-        x = x.float().contiguous()
-        stepper.set_condition(mask.to(torch.uint8).contiguous(), x.clone())
-    x_mean = torch.empty_like(x)
-    stepper.reset(0)
-    torch.cuda.synchronize()
-    setup_s = time.perf_counter() - t_setup
+    lib = load()
 
-    side = torch.cuda.Stream(device=dev) if args.graph else None      # stream capture needs a real stream
-    run_step = stepper.step
-    if args.graph:
-        def run_step(a, b):
-            with torch.cuda.stream(side):
-                stepper.step_graph(a, b)
-        torch.cuda.synchronize()
-        for _ in range(2):                                            # eager step + capture
-            run_step(x, x_mean)
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        run_step(x, x_mean)
-    if dist is not None:
-        D.gather_samples(x_mean, dist)                       # RCCL communicator set-up is not part of a run
-    # the schedule tables hold N steps: the timed region starts at step 0 of a run and rewinds every N steps
-    stepper.reset(0)
-    D.barrier(dist, dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i and i % N == 0:
-            stepper.reset(0)
-        run_step(x, x_mean)
-    if side is not None:
-        torch.cuda.current_stream().wait_stream(side)
-    gathered = D.gather_samples(x_mean, dist)                # the single collective of a run (no-op at N = 1)
-    D.barrier(dist, dev)
-    dt = D.max_over_ranks(time.perf_counter() - t0, dist, dev)
-    finite = bool(torch.isfinite(gathered).all().item()) and gathered.shape[0] == B * world
-
+    job = Job(args.workload, args.dtype, dev, rank, args.batch)
+    B, N = job.B, job.N
+    dt, finite = job.timed(args.steps, args.warmup, dist, args.graph)
     ms_per_step = dt / args.steps * 1e3
-    total_chains = B * world
-    value = total_chains / (N * dt / args.steps)
+    value = B * world / (N * dt / args.steps)
     alg = ALG_GFLOP[args.workload] * 1e9
     out = {
-        "metric": "6D backbone samples/sec (128-res, 1000-step)" if L == 128 else f"6D backbone samples/sec ({L}-res, {N}-step)",
+        "metric": "6D backbone samples/sec (128-res, 1000-step)" if job.L == 128 else f"6D backbone samples/sec ({job.L}-res, {N}-step)",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic (hash-generated non-degenerate weights, N(0,1) text embeddings, on-device Philox noise)",
-        "config": {"workload": f"{args.workload}: {fname} L={L} N={N} chains/GPU={B} C={C_} text_tokens={T} "
-                               f"condition={cond_kind or 'none'}; step = 1 PC step (2 score evals + SDE updates); "
-                               f"sample = {N} PC steps",
-                   "samples_per_min": value * 60.0, "setup_s": setup_s, "finite": finite,
+        "config": {"workload": job.describe(),
+                   "samples_per_min": value * 60.0, "setup_s": job.setup_s, "finite": finite,
                    "mfma_frac_end_to_end": value * 2 * N * alg / world / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12),
-                   "device_gib": model.device_bytes() / 2 ** 30},
+                   "device_gib": job.model.device_bytes() / 2 ** 30},
+        # roofline.traffic is NOT measured by this run: it is the HBM byte count of the committed rocprofv3 --pmc passes of this
+        # same command (profiles/), see roofline.traffic_from_profile
+        "traffic_measured_in_run": False,
     }
+    if rank == 0 and not args.graph:
+        out["dispatches_per_step"] = job.stepper.count_dispatches(job.x, job.x_mean)     # graph nodes of one captured PC step
 
     if rank == 0 and not args.no_roofline:
-        # dominant kernel = the LDS-DMA implicit-GEMM 3x3 convolution (gemm_dma_kernel, modes 1/2):
-        # every launch of one PC step timed with HIP events on the launch stream
-        lib = load()
-        stepper.reset(0)
-        check(lib.t2p_profile_begin())
-        nprof = 1
-        for _ in range(nprof):
-            stepper.step(x, x_mean)
-        o = (C.c_double * 9)()
-        check(lib.t2p_profile_end(o))
-        conv_ms, conv_fl, conv_n, g_ms, g_fl, g_n, c1_ms, c1_fl, c1_n = list(o)
-        dom, dom_name = (C.c_double * 4)(), C.create_string_buffer(256)
-        check(lib.t2p_profile_dominant(dom, dom_name, 256))
-        dom_ms, dom_fl, dom_n, dom_bytes = list(dom)
-        att = (C.c_double * 3)()
-        check(lib.t2p_profile_attention(att))
-        att_ms, att_fl, att_n = list(att)
-        if args.shapes:           # the GEMM / convolution launches of the profiled steps by operand shape (tools/shapes_table.py)
-            buf = C.create_string_buffer(1 << 20)
-            check(lib.t2p_profile_shapes(buf, len(buf)))
-            os.makedirs(os.path.dirname(os.path.abspath(args.shapes)), exist_ok=True)
-            with open(args.shapes, "w") as f:
-                f.write(f"# {args.workload} {args.dtype} chains={B}: {nprof} profiled PC step(s)\n" + buf.value.decode())
-        if args.layers:           # per-block times of one PC step (tools/layer_table.py)
-            check(lib.t2p_profile_layers_begin())
-            stepper.step(x, x_mean)
-            buf = C.create_string_buffer(1 << 20)
-            check(lib.t2p_profile_layers_end(buf, len(buf)))
-            os.makedirs(os.path.dirname(os.path.abspath(args.layers)), exist_ok=True)
-            with open(args.layers, "w") as f:
-                f.write(f"# {args.workload} {args.dtype} chains={B}: one PC step (2 score evaluations)\n" + buf.value.decode())
-        peak = MFMA_PEAK_TFLOPS[args.dtype]
-        if conv_n == 0:            # fp32 mode: every convolution runs on the register-staged exact-f32 kernel
-            conv_ms, conv_fl, conv_n, c1_ms, c1_fl, c1_n = c1_ms, c1_fl, c1_n, 0.0, 0.0, 0.0
-            kname = "gemm_kernel<float> (implicit-GEMM 3x3 convolution, v_mfma_f32_32x32x2_f32)"
-        else:
-            kname = "gemm_dma_kernel (LDS-DMA implicit-GEMM 3x3 convolution)"
-        all_conv = {"achieved": conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0, "launches_per_step": conv_n / nprof,
-                    "avg_launch_ms": conv_ms / max(conv_n, 1), "share_of_step_ms": conv_ms / nprof}
-        if dom_n > 0:
-            # the dominant instantiation by name: its average launch duration is the figure to hold against
-            # the rocprofv3 --stats average of the same kernel in profiles/<round>_kernel_stats.csv
-            kname = dom_name.value.decode()
-            conv_ms, conv_fl, conv_n = dom_ms, dom_fl, dom_n
-        ach = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        traffic = None
+        r = kernel_roofline(job, job.stepper, lib, MFMA_PEAK_TFLOPS[args.dtype], args.shapes, args.layers)
         tfile = sorted(__import__("glob").glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        r["traffic_from_profile"] = None
         if tfile and args.workload == "cfg2" and args.dtype == "f16" and B == 32:
             # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
             # (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction; profiles/README.md)
             t = json.load(open(tfile[-1]))
-            if kname in t:
-                traffic = t[kname]["hbm_bytes_per_launch"]
-        out["roofline"] = {
-            "bound": "mfma", "kernel": kname,
-            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-            # not measured in this run: HBM bytes per launch from the committed rocprofv3 --pmc passes of this command
-            "traffic_from_profile": ({"bytes_per_launch": traffic, "file": os.path.relpath(tfile[-1], ROOT)} if traffic else None),
-            "launches_per_step": conv_n / nprof, "avg_launch_ms": conv_ms / max(conv_n, 1),
-            "algorithmic_gflop_per_launch": conv_fl / max(conv_n, 1) / 1e9,
-            "algorithmic_bytes_per_launch": (dom_bytes / dom_n) if dom_n > 0 else None,
-            "share_of_step_ms": conv_ms / nprof,
-            "all_conv3x3_launches": all_conv,
-            "other_gemm": {"achieved": g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0, "launches_per_step": g_n / nprof,
-                           "share_of_step_ms": g_ms / nprof, "frac": (g_fl / (g_ms * 1e-3) / 1e12 / peak) if g_ms > 0 else 0.0},
-            "conv_on_v1_kernel": {"launches_per_step": c1_n / nprof, "share_of_step_ms": c1_ms / nprof},
-            # fused self / text cross-attention (attn_flash_kernel): the "attention roofline" of the north star
-            "attention": {"achieved": att_fl / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0, "launches_per_step": att_n / nprof,
-                          "share_of_step_ms": att_ms / nprof, "frac": (att_fl / (att_ms * 1e-3) / 1e12 / peak) if att_ms > 0 else 0.0},
-        }
+            if r["kernel"] in t:
+                r["traffic"] = t[r["kernel"]]["hbm_bytes_per_launch"]
+                r["traffic_from_profile"] = {"bytes_per_launch": r["traffic"], "file": os.path.relpath(tfile[-1], ROOT)}
+        out["roofline"] = r
+    if world > 1 and args.workload == "cfg2" and not args.no_cfg3:
+        # BASELINE.json configs[2] (cond_length.yml, 32 chains per GPU, length condition): the workload the north star's
+        # ">= 1000 samples/min on 8 GPUs" is about, measured by the same ranks with the same bracketing; cfg2 stays the headline
+        job3 = Job("cfg3", args.dtype, dev, rank)
+        dt3, fin3 = job3.timed(args.steps, args.warmup, dist, 0)
+        v3 = job3.B * world / (job3.N * dt3 / args.steps)
+        out["cfg3"] = {"value": v3, "unit": "samples/s", "samples_per_min": v3 * 60.0, "ms_per_step": dt3 / args.steps * 1e3,
+                       "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "finite": fin3, "workload": job3.describe()}
+        del job3
     if rank == 0 and world == 1 and not args.no_f32 and args.dtype != "f32":
-        # the same workload on the exact-f32 engine (v_mfma_f32_32x32x2_f32: the reference's own arithmetic type),
-        # so that both precisions are on record; a few steps are enough (every step has the same cost)
-        del stepper
-        m32 = HipScoreModel(cfg, dtype="f32", device=str(dev))
-        m32.load_state_dict(sd)
-        m32.set_context(ctx)
-        st32 = sampling.PCStepper(m32, sde, B, cfg.sampling.snr, cfg.sampling.n_steps_each, cfg.sampling.probability_flow,
-                                  cfg.sampling.noise_removal, 1e-5, seed=D.rank_seed(0, rank))
+        # the same workload on the exact-f32 engine (v_mfma_f32_32x32x2_f32: the reference's own arithmetic type), timed over
+        # the same kind of region, with its own kernel roofline against the 157.3 TFLOP/s f32 matrix peak
+        job.stepper = None
+        m32 = HipScoreModel(job.cfg, dtype="f32", device=str(dev))
+        m32.load_state_dict(job.sd)
+        m32.set_context(job.ctx)
+        st32 = job.new_stepper(m32, rank)
+        if job.cond:
+            st32.set_condition(*job.cond)
         st32.reset(0)
-        st32.step(x, x_mean)
+        st32.step(job.x, job.x_mean)                          # warm-up (fills the activation pool)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.f32_steps):
-            st32.step(x, x_mean)
+            st32.step(job.x, job.x_mean)
         torch.cuda.synchronize()
         d32 = (time.perf_counter() - t0) / args.f32_steps
         v32 = B / (N * d32)
-        out["f32"] = {"value": v32, "unit": "samples/s", "ms_per_step": d32 * 1e3, "steps": args.f32_steps,
-                      "mfma_frac_end_to_end": v32 * 2 * N * alg / (MFMA_PEAK_TFLOPS["f32"] * 1e12), "peak": MFMA_PEAK_TFLOPS["f32"]}
+        out["f32"] = {"value": v32, "unit": "samples/s", "ms_per_step": d32 * 1e3, "steps": args.f32_steps, "warmup": 1, "dtype": "f32",
+                      "mfma_frac_end_to_end": v32 * 2 * N * alg / (MFMA_PEAK_TFLOPS["f32"] * 1e12), "peak": MFMA_PEAK_TFLOPS["f32"],
+                      "finite": bool(torch.isfinite(job.x_mean).all().item()),
+                      "dispatches_per_step": st32.count_dispatches(job.x, job.x_mean)}
+        if not args.no_roofline:
+            out["f32"]["roofline"] = kernel_roofline(job, st32, lib, MFMA_PEAK_TFLOPS["f32"])
         del st32, m32
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(cfg, sd, ctx_cpu, N)
+        out["cpu_baseline"] = cpu_baseline(job.cfg, job.sd, job.ctx_cpu, N)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

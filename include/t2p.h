@@ -136,6 +136,9 @@ int t2p_sampler_step_graph(t2p_sampler* s, float* x, float* x_mean, void* stream
 /* Full run: x must hold the (already conditioned) prior sample on entry when `prior_given`, else it
  * is drawn on device (randn * sigma_max, then mask applied).  out receives x_mean (denoise) or x. */
 int t2p_sampler_run(t2p_sampler* s, float* x, float* out, int prior_given, int n_steps, void* stream);
+/* measurement: the number of device dispatches (graph nodes) one PC step (sampling.py:279-285) enqueues; the step is captured
+ * on `stream` (not the default stream) and discarded, nothing executes; call after at least one eager step */
+int t2p_sampler_count_dispatches(t2p_sampler* s, float* x, float* x_mean, void* stream, int* n_out);
 
 /* ---- individual operators (parity tests call these through the same ABI) -------------------- */
 int t2p_op_gemm(int dtype, const void* A, int a_f32, const void* Bw, void* C, int c_f32, int M, int N, int K,
@@ -155,6 +158,16 @@ int t2p_op_conv3x3(int dtype, const void* x, int a_f32, const void* w, const flo
 int t2p_op_conv3x3_shortcut(int dtype, const void* a, const void* w, const float* bias, const void* x0, int CX0,
                             const void* x1, int CX1, float alpha, void* out, int c_f32, int batch, int H, int W, int C,
                             int Cout, void* stream);
+/* a 3x3 convolution FOLLOWED by a GroupNorm (+SiLU) of its output, as inside ResnetBlockBigGANpp.forward (layers.py:304-321:
+ * h = Conv_0(...) + Dense_0(temb); h = act(GroupNorm_1(h)), and the block output -> the next block's GroupNorm_0): low-resolution
+ * convolutions run with the K loop split over workgroups, and the pass that sums the partial tiles applies the norm too.
+ * a [batch][H][W][C] and w [Cout][9 C] in the 16-bit compute dtype; bias [Cout], bias_bn [batch][Cout] (time-embedding bias) and
+ * residual [batch][H][W][Cout] (compute dtype) optional; out (fp32 or compute dtype, may be null) = alpha (conv + biases + residual);
+ * normed (compute dtype) = act(GroupNorm(out)); col_stats optional (per-64-row column sums of out, H W % 64 == 0).
+ * T2P_ERR_INVALID when the launch would not take that plan (no workspace: t2p_debug_set(10, MiB); K loop too short; H W > 256) */
+int t2p_op_conv3x3_groupnorm(int dtype, const void* a, const void* w, const float* bias, const float* bias_bn, const void* residual,
+                             float alpha, int upsample, int groups, const float* gamma, const float* beta, float eps, int silu,
+                             void* out, int out_f32, void* normed, float* col_stats, int batch, int H, int W, int C, int Cout, void* stream);
 /* the network's input convolution (pre_conv, ncsnpp.py:230: 3x3, C = 5 or 8 input channels -> nf) straight from the NCHW fp32
  * sample, in fp32 arithmetic: x [batch][C][H][W] fp32; w_tcn [3*3][C][nf] fp32 (tap-major); out NHWC [batch][H][W][nf] in
  * out_dtype.  col_stats (optional; W % 64 == 0, nf | 256): [batch H W / 64][nf][2] fp32 = (sum, sum of squares) of the fp32
@@ -244,6 +257,10 @@ int t2p_profile_shapes(char* buf, int len);
 /* per-block timing of the score network (UNetModel.forward, ncsnpp.py:220-263): HIP events on the launch stream at every block
  * boundary between _begin and _end; _end synchronises the device and writes CSV lines
  * "prefix,kind,map side,in channels,out channels,ms" in launch order (pre = embedding + input convolution, head = out.*) */
+/* development: from now on every score evaluation also writes the output of block number `block_index` (launch order of
+ * t2p_profile_layers_*, the pre / head entries not counted; -1 = off) to `dst` as fp32 NHWC [batch][H][W][C] (capacity in floats);
+ * shape4 (optional) receives {C, H, W, stored-in-16-bit flag} of the LAST tap taken */
+int t2p_debug_tap(int block_index, float* dst, int64_t capacity, int64_t* shape4);
 int t2p_profile_layers_begin(void);
 int t2p_profile_layers_end(char* buf, int len);
 

@@ -105,3 +105,48 @@ def test_cli_captions_and_decode(tmp_path, tiny_tokenizer_dir):
     assert want["L"] == cfg.data.min_res_num + 5 - 1
     for k in ("dist", "omega", "theta", "phi", "dist_abs", "omega_abs", "theta_abs", "phi_abs"):
         assert np.array_equal(got[k], want[k]), k
+
+
+def test_cli_inpainting_from_known_maps(tmp_path):
+    """--inpaint_coords + --mask_info: the conditions the reference builds from --pdb (utils.py:84-137 -> sampling.py:259-287),
+    driven from the entry point on a model trained with ["length", "inpainting"]."""
+    from text2protein_amd.config import tiny_config
+    cfg = tiny_config(**{"model.num_scales": 4, "model.condition": ["length", "inpainting"], "data.num_channels": 8})
+    cfg_path = tmp_path / "tiny_inp.yml"
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(yaml.safe_load(__import__("json").dumps(cfg)), f)
+    L, C = cfg.data.max_res_num, 8
+    n = L - 3
+    coords = torch.rand(1, C, L, L) * 2 - 1
+    torch.save({"coords_6d": coords, "lengths": [n]}, tmp_path / "known.pt")
+    out = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(ROOT, "sampling_6d.py"), str(cfg_path), "synthetic", "--batch_size", "2", "--dtype", "f32",
+           "--context_tokens", "4", "--outdir", str(out), "--inpaint_coords", str(tmp_path / "known.pt"), "--mask_info", "1:2,5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    with open(out / "sampled_1.pkl", "rb") as f:
+        t = pickle.load(f)[0]
+    sel = torch.zeros(L, dtype=torch.bool)
+    sel[[1, 2, 5]] = True
+    inside = torch.arange(L) < n
+    free = (inside[:, None] & inside[None, :]) & (sel[:, None] | sel[None, :])      # conditional_mask of sampling.py:259-275
+    assert torch.isfinite(t).all()
+    assert torch.equal(t[:-1][:, ~free], coords[0, :-1][:, ~free])                   # everything else is the known map
+    assert torch.equal(t[-1], coords[0, -1])                                        # the last channel is never free
+    assert float((t[:-1][:, free] - coords[0, :-1][:, free]).abs().max()) > 1e-3    # the selected residues were sampled
+    # without a source of known maps the flag is an error, not a silent no-op
+    r2 = subprocess.run(cmd[:-4] + ["--mask_info", "1:2"], capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert r2.returncode != 0 and "--inpaint_coords" in r2.stderr + r2.stdout
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the RCCL path (runs the first time a multi-GPU box is seen)")
+def test_bench_two_ranks_over_rccl():
+    """`python bench.py --gpus 2` as the driver starts it: two rank processes, nccl (= RCCL) backend, the all_gather of the run."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-roofline", "--no-cfg3"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("T2P_DIST_BACKEND", "T2P_FORCE_DEVICE")})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["config"]["finite"] is True and rec["value"] > 0

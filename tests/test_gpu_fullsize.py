@@ -85,6 +85,44 @@ def test_full_size_sampler_invariants(full):
     assert float(out[free].abs().max()) > 1.0                   # the free region evolved from the sigma_max prior
 
 
+def test_cfg5_sampler_at_full_size():
+    """BASELINE configs[4]: the C = 8 cond_length_inpainting model at its per-GPU batch (16 chains, L = 128) with the length +
+    inpainting conditions, 3 PC steps of the fused sampler: what sampling.py:259-287 guarantees whatever the network does --
+    the known region and the mask channel come back exactly, everything outside the length mask stays at its initial value,
+    the free region moved -- plus bitwise reproducibility, and the class route (operator ABI) agreeing with the fused one."""
+    from text2protein_amd import sampling, sde_lib, synth
+    from text2protein_amd.conditions import synthetic_condition
+    from text2protein_amd.config import load_config
+    cfg = load_config(os.path.join(ROOT, "configs", "cond_length_inpainting.yml"), **{"data.max_res_num": 128, "model.num_scales": 1000})
+    cfg.device = "cuda:0"
+    B, C, L, T = 16, 8, 128, 512
+    assert cfg.data.num_channels == C and cfg.model.condition == ["length", "inpainting"]
+    sd = synth.synth_state_dict(cfg, 0)
+    ctx = synth.synth_context(B, T, cfg.model.context_dim, 31).cuda()
+    m = _model(cfg, sd, "f16")
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=cfg.model.num_scales)
+    cond = synthetic_condition(cfg, B, "length+inpainting", "cuda:0", length=100)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, C, L, L), 1e-5, seed=5)
+    out, nfe = fn(m, condition=cond, context=ctx, n_iter=3, call_index=0)
+    again, _ = fn(m, condition=cond, context=ctx, n_iter=3, call_index=0)
+    torch.cuda.synchronize()
+    assert nfe == 2000 and torch.isfinite(out).all() and torch.equal(out, again)
+    # mask_inpaint is True where a pixel is to be inpainted (pairs with a selected residue, "1:5,10:15" = 11 residues)
+    length, selected, coords = cond["length"], cond["inpainting"]["mask_inpaint"], cond["inpainting"]["coords_6d"]
+    free = (length & selected).unsqueeze(1).expand_as(out).clone()
+    free[:, -1] = False
+    assert torch.equal(out[~free], coords[~free])               # known residues, the outside of the length mask, the mask channel
+    assert float(out[free].abs().max()) > 1.0 and float((out[free] - coords[free]).abs().mean()) > 1.0
+    assert int(free[0].sum()) == 7 * (100 * 100 - 89 * 89)      # 7 data channels x pairs inside the length mask with a selected residue
+    fn_c = sampling.get_sampling_fn(cfg, sde, (B, C, L, L), 1e-5, seed=5, force_classes=True)
+    out_c, _ = fn_c(m, condition=cond, context=ctx, n_iter=3, call_index=0)
+    torch.cuda.synchronize()
+    assert torch.equal(out_c[~free], coords[~free])
+    e = rel_l2(out_c[free], out[free])
+    print(f"cfg5 shape, 3 PC steps at 16 chains: class route vs fused route rel-L2 = {e:.3e}")
+    assert e < 1e-3
+
+
 def test_midsize_splitk_plan_matches_unsplit(full):
     """24 chains put the 16x16 level at 48 tiles of 256x256: those convolutions then run as 256x256 tiles
     with the K loop split (GroupNorm statistics produced by the split-K second pass).  Both plans use the

@@ -553,3 +553,63 @@ def test_self_attention_on_stacked_qkv(lib, dt, B, heads, n, d):
                                     n, n, d, scale, P(ws), None))
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), out2.cpu())
+
+
+def test_conv3x3_followed_by_groupnorm_in_the_second_pass(lib):
+    """Low-resolution 3x3 convolutions run with the K loop split over workgroups; the pass that sums the partial tiles also applies
+    the GroupNorm (+SiLU) that follows in ResnetBlockBigGANpp.forward (layers.py:304-321) -- t2p_op_conv3x3_groupnorm.  Against
+    torch fp64 on the same 16-bit operands: the raw output (with time-embedding bias, residual, 1/sqrt 2), its normalised +
+    activated form, and the per-64-row column sums a later GroupNorm over a concatenation reads."""
+    try:
+        check(lib, lib.t2p_debug_set(10, 256))
+        g = torch.Generator().manual_seed(77)
+        cases = [(4, 16, 16, 256, 256, 32, 1, True, 0), (3, 8, 8, 128, 128, 32, 1, True, 0), (8, 4, 4, 256, 256, 32, 0, False, 0),
+                 (2, 16, 16, 512, 256, 32, 1, True, 0), (2, 8, 8, 256, 64, 16, 0, False, 0), (2, 16, 16, 128, 256, 32, 1, False, 1)]
+        for dt in (2, 1):
+            td = TDT[dt]
+            for (B, H, W, Cin, Cout, G, silu, with_res, up) in cases:
+                Hs, Ws = (H // 2, W // 2) if up else (H, W)
+                a = torch.randn(B, Cin, Hs, Ws, generator=g).to(td)
+                w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(td)
+                bias, tb = torch.randn(Cout, generator=g), torch.randn(B, Cout, generator=g)
+                res = torch.randn(B, Cout, H, W, generator=g).to(td) if with_res else None
+                gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3
+                alpha = 0.5 ** 0.5 if with_res else 1.0
+                src = F.interpolate(a.double(), scale_factor=2, mode="nearest") if up else a.double()
+                raw = F.conv2d(src, w.double(), bias.double(), padding=1) + tb.double()[:, :, None, None]
+                if with_res:
+                    raw = raw + res.double()
+                raw = raw * alpha
+                normed = F.group_norm(raw, G, gamma.double(), beta.double(), eps=1e-6)
+                if silu:
+                    normed = F.silu(normed)
+                wk = dev(w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin))
+                for out_f32 in (1, 0, None):                       # None: the raw product is not wanted (GroupNorm_1's input)
+                    out = None if out_f32 is None else torch.full((B, H, W, Cout), float("nan"), device="cuda", dtype=torch.float32 if out_f32 else td)
+                    nrm = torch.full((B, H, W, Cout), float("nan"), device="cuda", dtype=td)
+                    want_cs = (H * W) % 64 == 0 and out_f32 is not None
+                    cs = torch.full((B * H * W // 64, Cout, 2), float("nan"), device="cuda") if want_cs else None
+                    check(lib, lib.t2p_op_conv3x3_groupnorm(dt, P(dev(a.permute(0, 2, 3, 1))), P(wk), P(dev(bias)), P(dev(tb)),
+                                                            P(dev(res.permute(0, 2, 3, 1))) if with_res else None, alpha, up, G, P(dev(gamma)),
+                                                            P(dev(beta)), 1e-6, silu, P(out) if out is not None else None, int(bool(out_f32)),
+                                                            P(nrm), P(cs) if want_cs else None, B, H, W, Cin, Cout, None))
+                    torch.cuda.synchronize()
+                    key = (dt, B, H, W, Cin, Cout, G, silu, with_res, up, out_f32)
+                    e_n = rel_l2(nrm.float().cpu(), normed.permute(0, 2, 3, 1))
+                    assert e_n < (6e-4 if dt == 2 else 5e-3), (key, e_n)          # fp32 arithmetic, one rounding to 16 bits
+                    if out is not None:
+                        e_r = rel_l2(out.float().cpu(), raw.permute(0, 2, 3, 1))
+                        assert e_r < (3e-6 if out_f32 else (6e-4 if dt == 2 else 5e-3)), (key, e_r)
+                    if want_cs:
+                        r64 = raw.permute(0, 2, 3, 1).reshape(B * H * W // 64, 64, Cout)
+                        ref_cs = torch.stack([r64.sum(1), (r64 * r64).sum(1)], -1)
+                        assert rel_l2(cs.cpu(), ref_cs) < 1e-5, key
+        # a launch that does not take the split-K plan is refused (no workspace here), not computed without the norm
+        check(lib, lib.t2p_debug_set(10, 0))
+        z = torch.zeros(1, 8, 8, 64, device="cuda", dtype=torch.float16)
+        zw = torch.zeros(64, 9 * 64, device="cuda", dtype=torch.float16)
+        one = torch.ones(64, device="cuda")
+        assert lib.t2p_op_conv3x3_groupnorm(2, P(z), P(zw), None, None, None, 1.0, 0, 16, P(one), P(one), 1e-6, 1, None, 0, P(z), None,
+                                            1, 8, 8, 64, 64, None) != 0
+    finally:
+        lib.t2p_debug_set(10, 0)

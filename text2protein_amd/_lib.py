@@ -61,8 +61,11 @@ SIGNATURES = {
     "t2p_sampler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "t2p_sampler_step_graph": (_i, [_vp, _vp, _vp, _vp]),
     "t2p_sampler_run": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "t2p_sampler_count_dispatches": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int)]),
     "t2p_op_gemm": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _vp, _f, _vp]),
     "t2p_op_conv3x3_shortcut": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "t2p_op_conv3x3_groupnorm": (_i, [_i, _vp, _vp, _vp, _vp, _vp, C.c_float, _i, _i, _vp, _vp, C.c_float, _i, _vp, _i, _vp, _vp,
+                                      _i, _i, _i, _i, _i, _vp]),
     "t2p_op_input_conv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "t2p_op_gemm_r16": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _vp, _f, _vp]),
     "t2p_op_conv3x3": (_i, [_i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -88,6 +91,7 @@ SIGNATURES = {
     "t2p_profile_dominant": (_i, [C.POINTER(C.c_double), C.c_char_p, C.c_int]),
     "t2p_profile_attention": (_i, [C.POINTER(C.c_double)]),
     "t2p_profile_shapes": (_i, [C.c_char_p, C.c_int]),
+    "t2p_debug_tap": (_i, [_i, _vp, C.c_int64, C.POINTER(C.c_int64)]),
     "t2p_profile_layers_begin": (_i, []),
     "t2p_profile_layers_end": (_i, [C.c_char_p, C.c_int]),
     "t2p_op_convert": (_i, [_vp, _vp, _i, _i64, _vp]),

@@ -44,9 +44,18 @@ def unit_hash(src: str, flags) -> str:
     """Identity of one object file: its source, every header and the flags (unchanged units are not recompiled)."""
     h = hashlib.sha256()
     h.update(" ".join(flags).encode())
-    for f in [src] + HEADERS:
-        with open(os.path.join(CSRC, f), "rb") as fh:
-            h.update(fh.read())
+    seen, todo = [], [os.path.join(CSRC, src)]
+    while todo:                                   # the source and the local headers it includes, transitively
+        f = os.path.normpath(todo.pop())
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.append(f)
+        with open(f, "rb") as fh:
+            data = fh.read()
+        h.update(os.path.relpath(f, CSRC).encode())
+        h.update(data)
+        for inc in re.findall(rb'^\s*#\s*include\s+"([^"]+)"', data, re.M):
+            todo.append(os.path.join(os.path.dirname(f), inc.decode()))
     return h.hexdigest()
 
 

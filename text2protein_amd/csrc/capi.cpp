@@ -17,7 +17,8 @@ using namespace t2p;
     return T2P_ERR_STATE;                              \
   }
 
-namespace t2p { extern bool g_pre_conv_mfma, g_gn_apply_cols; void layer_profile_begin(); int layer_profile_end(std::string* out); }
+namespace t2p { extern bool g_pre_conv_mfma, g_gn_apply_cols; void layer_profile_begin(); int layer_profile_end(std::string* out);
+void debug_tap_set(int index, float* dst, long capacity); void debug_tap_shape(long out[4]); }
 extern "C" {
 
 const char* t2p_last_error(void) { return get_last_error(); }
@@ -163,6 +164,13 @@ int t2p_sampler_step_graph(t2p_sampler* s, float* x, float* x_mean, void* stream
   API_END
 }
 
+int t2p_sampler_count_dispatches(t2p_sampler* s, float* x, float* x_mean, void* stream, int* n_out) {
+  API_BEGIN
+  T2P_REQUIRE(s, "null sampler");
+  return s->impl.count_dispatches(x, x_mean, (hipStream_t)stream, n_out);
+  API_END
+}
+
 int t2p_sampler_run(t2p_sampler* s, float* x, float* out, int prior_given, int n_steps, void* stream) {
   API_BEGIN
   T2P_REQUIRE(s, "null sampler");
@@ -228,6 +236,23 @@ int t2p_op_conv3x3_shortcut(int dtype, const void* a, const void* w, const float
   T2P_TRY(attach_op_ws(p));
   T2P_REQUIRE(gemm_can_fuse_shortcut(p), "this convolution does not take the shortcut segment (LDS-DMA 3x3 convolutions only)");
   p.X0 = x0; p.CX0 = CX0; p.ldx0 = CX0; p.X1 = x1; p.CX1 = CX1; p.ldx1 = CX1;
+  return launch_gemm(p, (hipStream_t)stream);
+  API_END
+}
+
+int t2p_op_conv3x3_groupnorm(int dtype, const void* a, const void* w, const float* bias, const float* bias_bn, const void* residual,
+                             float alpha, int upsample, int groups, const float* gamma, const float* beta, float eps, int silu,
+                             void* out, int out_f32, void* normed, float* col_stats, int batch, int H, int W, int C, int Cout, void* stream) {
+  API_BEGIN
+  GemmParams p;
+  p.dtype = dtype; p.A0 = a; p.a_f32 = 0; p.C0 = C; p.lda0 = C; p.taps = 9; p.H = H; p.W = W; p.a_up = upsample;
+  p.Bw = w; p.ldb = 9L * C; p.M = batch * H * W; p.N = Cout; p.bias_n = bias; p.rows_per_batch = H * W;
+  p.bias_bn = bias_bn; p.ld_bn = Cout;
+  p.R = (const float*)residual; p.r_lowp = residual ? 1 : 0; p.ldr = Cout;
+  p.alpha = alpha; p.C = out; p.c_f32 = out_f32; p.ldc = Cout; p.col_stats = col_stats;
+  T2P_TRY(attach_op_ws(p));
+  T2P_REQUIRE(gemm_fuses_post_gn(p, groups), "this convolution does not take the split-K plan whose second pass applies a GroupNorm");
+  p.gn_gamma = gamma; p.gn_beta = beta; p.gn_groups = groups; p.gn_silu = silu; p.gn_eps = eps; p.gn_out = normed;
   return launch_gemm(p, (hipStream_t)stream);
   API_END
 }
@@ -441,6 +466,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 25) { g_qkv_fused = value != 0; return T2P_OK; }
   if (key == 26) { t2p::g_pre_conv_mfma = value != 0; return T2P_OK; }
   if (key == 27) { t2p::g_gn_apply_cols = value != 0; return T2P_OK; }
+  if (key == 28) { set_gemm_post_gn(value != 0); return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) {
 #ifndef T2P_ABLATION
@@ -498,6 +524,18 @@ int t2p_profile_shapes(char* buf, int len) {
   API_BEGIN
   T2P_REQUIRE(buf && len > 0, "null argument");
   return profile_shapes(buf, len);
+  API_END
+}
+
+int t2p_debug_tap(int block_index, float* dst, int64_t capacity, int64_t* shape4) {
+  API_BEGIN
+  if (shape4) {
+    long sh[4];
+    t2p::debug_tap_shape(sh);
+    for (int i = 0; i < 4; ++i) shape4[i] = sh[i];
+  }
+  t2p::debug_tap_set(block_index, dst, (long)capacity);
+  return T2P_OK;
   API_END
 }
 

@@ -40,6 +40,15 @@ int ensure_dynamic_lds(const void* kernel, int bytes) {
   return T2P_OK;
 }
 
+// ---- development tap (t2p_debug_tap): the output of block number `g_tap_index` of the next evaluations, widened to fp32 ----
+static int g_tap_index = -1;
+static float* g_tap_dst = nullptr;
+static long g_tap_cap = 0;
+static long g_tap_shape[4] = {0, 0, 0, 0};     // C, H, W, stored in 16 bits
+static int g_tap_counter = 0;
+void debug_tap_set(int index, float* dst, long capacity) { g_tap_index = index; g_tap_dst = dst; g_tap_cap = capacity; }
+void debug_tap_shape(long out[4]) { for (int i = 0; i < 4; ++i) out[i] = g_tap_shape[i]; }
+
 // ---- per-layer timing (development / bench: t2p_profile_layers_*): HIP events on the launch stream at block boundaries ----
 struct LayerRec { std::string label; hipEvent_t e0, e1; };
 static bool g_layer_prof = false;
@@ -637,6 +646,11 @@ int Engine::group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps,
   T2P_REQUIRE(C == n.C, "GroupNorm channel mismatch");
   T2P_REQUIRE(!x1 || x1->lowp == x.lowp, "concatenated sources must share a storage type");
   T2P_REQUIRE(!x.lowp || dtype() != DT_F32, "16-bit activations exist in the 16-bit modes only");
+  if (x.pre_norm && !x1 && x.pre_for == &n && x.pre_silu == silu && !down && !raw_out) {
+    *out = x.pre_norm;              // the producing split-K second pass already applied this norm (GemmParams::gn_out)
+    x.pre_norm = nullptr;           // ownership passes to the caller, which returns it to the pool like any norm output
+    return T2P_OK;
+  }
   {
     // small maps (<= 64 pixels): statistics + apply in one launch instead of two or three latency-bound ones
     GroupNormApplyArgs g;
@@ -708,7 +722,7 @@ int Engine::group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps,
 }
 
 // ResnetBlockBigGANpp.forward (layers.py:303-327)
-int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, hipStream_t s) {
+int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, hipStream_t s, NormHint hint) {
   const int Cin = x.C + (skip ? skip->C : 0), Cout = L.out_ch;
   T2P_REQUIRE(Cin == L.in_ch, "res block input channels");
   T2P_REQUIRE(!(L.down && skip), "down block with concat input");
@@ -724,6 +738,7 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
   T2P_TRY(group_norm(x, skip, L.gn0, 1e-6f, 1, L.down, B, &a0, s, want_raw ? &xraw : nullptr));
   float* h1_stats = nullptr;
   bool h1_lowp = false;
+  void* a1_fused = nullptr;
   POOL_GET(h1, float*, (size_t)rows_out * Cout * 4);
   {
     GemmParams p;
@@ -736,6 +751,14 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     // h1 is read once more, by GroupNorm_1 only: when its statistics come out of this epilogue
     // (computed from the fp32 values) the tensor itself is stored in the compute dtype
     T2P_TRY(attach_ws(p));
+    if (dt != DT_F32 && gemm_fuses_post_gn(p, L.gn1.G)) {
+      // split-K convolution: its second pass applies GroupNorm_1 + SiLU itself (h1 is read by nothing else)
+      a1_fused = pool_.get((size_t)rows_out * Cout * dtype_size(dt));
+      if (!a1_fused) return T2P_ERR_HIP;
+      p.gn_gamma = L.gn1.gamma; p.gn_beta = L.gn1.beta; p.gn_groups = L.gn1.G; p.gn_silu = 1; p.gn_eps = 1e-6f; p.gn_out = a1_fused;
+      p.C = nullptr;
+      T2P_TRY(gemm(p, s));
+    } else {
     // (maps of <= 64 pixels go through the single-launch GroupNorm, which takes its own statistics:
     // h1 stays fp32 there so that they are still taken from unrounded values)
     if (g_lowp_h1 && dt != DT_F32 && g_fuse_gn_stats && gemm_fuses_col_stats(p) && (Ho * Wo) % 64 == 0 &&
@@ -746,11 +769,12 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     }
     T2P_TRY(gemm_stats(p, &h1_stats, s));
     if (h1_lowp && !h1_stats) return T2P_ERR_STATE;
+    }
   }
   pool_.put(a0);
   Act h1a{h1, Cout, Ho, Wo, h1_stats, h1_lowp};
-  void* a1 = nullptr;
-  T2P_TRY(group_norm(h1a, nullptr, L.gn1, 1e-6f, 1, 0, B, &a1, s));
+  void* a1 = a1_fused;
+  if (!a1) T2P_TRY(group_norm(h1a, nullptr, L.gn1, 1e-6f, 1, 0, B, &a1, s));
   free_act(h1a);
   // second convolution; set up here because the shortcut may ride in its K loop
   GemmParams pc;
@@ -823,11 +847,29 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
   pc.R = r; pc.ldr = Cout; pc.r_up = r_up;
   pc.r_lowp = (r == x.p ? x.lowp : rbuf_lowp) ? 1 : 0;   // identity shortcut: the block input itself
   pc.C = o; pc.c_f32 = olp ? 0 : 1; pc.ldc = Cout;
-  T2P_TRY(gemm_stats(pc, &o_stats, s));
+  void* pre = nullptr;
+  T2P_TRY(attach_ws(pc));
+  if (hint.norm && olp && hint.norm->C == Cout && gemm_fuses_post_gn(pc, hint.norm->G)) {
+    // the block that follows starts with a GroupNorm of this output alone: the split-K second pass applies it as well, and
+    // still writes the output itself (residual stream) with its column statistics (skip connections)
+    pre = pool_.get((size_t)rows_out * Cout * dtype_size(dt));
+    if (!pre) return T2P_ERR_HIP;
+    pc.gn_gamma = hint.norm->gamma; pc.gn_beta = hint.norm->beta; pc.gn_groups = hint.norm->G; pc.gn_silu = hint.silu; pc.gn_eps = 1e-6f;
+    if ((Ho * Wo) % 64 == 0 && g_fuse_gn_stats) {
+      o_stats = (float*)pool_.get((size_t)(rows_out / 64) * Cout * 2 * 4);
+      if (!o_stats) return T2P_ERR_HIP;
+      pc.col_stats = o_stats;
+    }
+    pc.gn_out = pre;
+    T2P_TRY(gemm(pc, s));
+  } else {
+    T2P_TRY(gemm_stats(pc, &o_stats, s));
+  }
   pool_.put(a1);
   pool_.put(rbuf);
   if (fused_shortcut) { pool_.put(xraw); pool_.put(xpooled); }
   *out = Act{o, Cout, Ho, Wo, o_stats, olp};
+  out->pre_norm = pre; out->pre_for = hint.norm; out->pre_silu = hint.silu;
   return T2P_OK;
 }
 
@@ -983,7 +1025,16 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   return T2P_OK;
 }
 
-int Engine::run_stage(Stage& st, Act& h, const Act* skip, int B, hipStream_t s) {
+// the first norm of `l` when it reads its input alone at full resolution (what a producer may apply ahead of time)
+static NormHint first_norm_of(const Layer* l, bool concat_input) {
+  NormHint h;
+  if (!l || concat_input || l->down) return h;
+  h.norm = &l->gn0;
+  h.silu = l->kind == 0 ? 1 : 0;
+  return h;
+}
+
+int Engine::run_stage(Stage& st, Act& h, const Act* skip, int B, hipStream_t s, const Layer* next_after) {
   Act cur = h;
   bool own = false;   // cur was produced inside this stage
   for (size_t i = 0; i < st.layers.size(); ++i) {
@@ -991,9 +1042,17 @@ int Engine::run_stage(Stage& st, Act& h, const Act* skip, int B, hipStream_t s) 
     Act nxt;
     LayerScope scope(L.prefix + (L.kind == 0 ? (L.up ? ",res_up," : L.down ? ",res_down," : ",res,") : L.kind == 1 ? ",attn," : ",st,") +
                      std::to_string(cur.H) + "," + std::to_string(L.in_ch) + "," + std::to_string(L.out_ch), s);
-    if (L.kind == 0) T2P_TRY(res_block(L, cur, i == 0 ? skip : nullptr, &nxt, B, s));
+    const Layer* nextL = i + 1 < st.layers.size() ? &st.layers[i + 1] : next_after;
+    if (L.kind == 0) T2P_TRY(res_block(L, cur, i == 0 ? skip : nullptr, &nxt, B, s, res_lowp() ? first_norm_of(nextL, false) : NormHint()));
     else if (L.kind == 1) T2P_TRY(attn_block(L, cur, &nxt, B, s));
     else T2P_TRY(st_block(L, cur, &nxt, B, s));
+    if (g_tap_index >= 0 && g_tap_counter++ == g_tap_index) {
+      const long n = (long)B * nxt.H * nxt.W * nxt.C;
+      g_tap_shape[0] = nxt.C; g_tap_shape[1] = nxt.H; g_tap_shape[2] = nxt.W; g_tap_shape[3] = nxt.lowp;
+      T2P_REQUIRE(g_tap_dst && n <= g_tap_cap, "tap buffer too small");
+      T2P_TRY(launch_widen(nxt.p, nxt.lowp ? dtype() : DT_F32, g_tap_dst, n, s));
+    }
+    drop_pre_norm(cur);              // (only if this layer did not take it)
     if (own) free_act(cur);
     cur = nxt;
     own = true;
@@ -1046,6 +1105,7 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
   T2P_REQUIRE(x && out && B > 0 && (labels || step_counter), "score arguments");
   const int L = cfg_.max_res_num, HW = L * L, Cx = cfg_.num_channels, N = cfg_.num_scales;
   const int R = labels ? B : 1;
+  g_tap_counter = 0;
   std::unique_ptr<LayerScope> pre_scope(new LayerScope("pre,pre," + std::to_string(L) + "," + std::to_string(Cx) + "," + std::to_string(nf_), s));
   POOL_GET(emb, float*, (size_t)R * nf_ * 4);
   POOL_GET(t1, float*, (size_t)R * temb_dim_ * 4);
@@ -1104,9 +1164,13 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
   std::vector<Act> hs;
   Act h{h0, nf_, L, L, h0_stats, h0_lowp};
   hs.push_back(h);
-  for (Stage& st : input_stages_) {
-    T2P_TRY(run_stage(st, h, nullptr, B, s));
+  for (size_t i = 0; i < input_stages_.size(); ++i) {
+    // the stage's last block may apply the first norm of the block that follows it (next input stage, or the mid stage)
+    // (run_stage owns the pre-applied norm its input carries: the first block takes it, or it is dropped there)
+    const Layer* next = i + 1 < input_stages_.size() ? &input_stages_[i + 1].layers[0] : &mid_stage_.layers[0];
+    T2P_TRY(run_stage(input_stages_[i], h, nullptr, B, s, next));
     hs.push_back(h);
+    hs.back().pre_norm = nullptr;      // the skip-stack copy does not own the pre-applied norm
   }
   // mid stage: its input stays on the skip stack
   T2P_TRY(run_stage(mid_stage_, h, nullptr, B, s));
@@ -1115,6 +1179,7 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
     hs.pop_back();
     T2P_REQUIRE(skip.C == st.skip_ch && skip.H == h.H, "skip stack mismatch");
     Act in = h;
+    in.pre_norm = nullptr;
     T2P_TRY(run_stage(st, h, &skip, B, s));
     free_act(in);
     free_act(skip);
@@ -1284,6 +1349,31 @@ int Sampler::step_graph(float* x, float* x_mean, hipStream_t s) {
   }
   T2P_HIP_CHECK(hipGraphLaunch(graph_exec_, s));
   ++host_step_;
+  return T2P_OK;
+}
+
+// number of kernel / memory nodes one PC step enqueues: the step is captured into a hipGraph (nothing executes) and its nodes
+// are counted.  Needs a non-default stream and a filled activation pool (one eager step before).
+int Sampler::count_dispatches(float* x, float* x_mean, hipStream_t s, int* n_out) {
+  T2P_REQUIRE(x && x_mean && n_out, "null argument");
+  T2P_REQUIRE(!allreduce_, "the captured step does not run the norm all-reduce hook");
+  T2P_REQUIRE(host_step_ >= 0 && host_step_ < cfg_.N, "PC step index beyond sde.N: call t2p_sampler_reset before another run");
+  hipGraph_t graph = nullptr;
+  T2P_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  const int step_before = host_step_;
+  const int rc = step(x, x_mean, nullptr, nullptr, s);
+  host_step_ = step_before;
+  const hipError_t ec = hipStreamEndCapture(s, &graph);
+  if (rc != T2P_OK) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  T2P_HIP_CHECK(ec);
+  size_t n = 0;
+  const hipError_t eg = hipGraphGetNodes(graph, nullptr, &n);
+  (void)hipGraphDestroy(graph);
+  T2P_HIP_CHECK(eg);
+  *n_out = (int)n;
   return T2P_OK;
 }
 

@@ -81,6 +81,15 @@ struct Act {  // an NHWC activation: fp32, or the compute dtype when `lowp`
   int C = 0, H = 0, W = 0;
   float* cstats = nullptr;   // optional per-64-row column sums of p (GemmParams::col_stats), for the consumer's GroupNorm
   bool lowp = false;         // p holds compute-dtype (16-bit) values instead of fp32
+  // optional: act(GroupNorm(p)) for the NEXT block's first norm, already produced by the split-K second pass that wrote p
+  // (GemmParams::gn_out); the consumer whose norm is `pre_for` takes it (and returns it to the pool), run_stage drops it otherwise
+  mutable void* pre_norm = nullptr;
+  const DevNorm* pre_for = nullptr;
+  int pre_silu = 0;
+};
+struct NormHint {            // the norm the consumer of a block's output will apply first
+  const DevNorm* norm = nullptr;
+  int silu = 0;
 };
 
 class Engine {
@@ -110,8 +119,8 @@ class Engine {
   int upload_f32(const std::vector<float>& v, float** out);
   const HostTensor* host(const std::string& name, std::vector<int64_t> shape);
 
-  int run_stage(Stage& st, Act& h, const Act* skip, int B, hipStream_t s);
-  int res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, hipStream_t s);
+  int run_stage(Stage& st, Act& h, const Act* skip, int B, hipStream_t s, const Layer* next_after = nullptr);
+  int res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, hipStream_t s, NormHint hint = NormHint());
   int attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s);
   int st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s);
   int group_norm(const Act& x, const Act* x1, const DevNorm& n, float eps, int silu, int down, int B, void** out,
@@ -120,7 +129,8 @@ class Engine {
   int attach_ws(GemmParams& p);
   // gemm() that also produces the output's GroupNorm column statistics when the kernel can (else *cstats = null)
   int gemm_stats(GemmParams& p, float** cstats, hipStream_t s);
-  void free_act(Act& a) { pool_.put(a.p); pool_.put(a.cstats); a.p = nullptr; a.cstats = nullptr; }
+  void free_act(Act& a) { pool_.put(a.p); pool_.put(a.cstats); pool_.put(a.pre_norm); a.p = nullptr; a.cstats = nullptr; a.pre_norm = nullptr; }
+  void drop_pre_norm(const Act& a) { pool_.put(a.pre_norm); a.pre_norm = nullptr; }
   int attention(const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, int B,
                 int heads, int nq, int nk, int d, float scale, hipStream_t s);
   int linear(const void* a, bool a_is_f32, const DevLinear& w, long rows, void* c, bool c_f32, const float* residual,
@@ -167,6 +177,7 @@ class Sampler {
   // condition) captures, later calls replay.  The step reads its index from the device counter.
   int step_graph(float* x, float* x_mean, hipStream_t s);
   int run(float* x, float* out, int prior_given, int n_steps, hipStream_t s);
+  int count_dispatches(float* x, float* x_mean, hipStream_t s, int* n_out);
   ~Sampler();
 
  private:

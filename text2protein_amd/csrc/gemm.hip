@@ -1945,6 +1945,135 @@ __global__ __launch_bounds__(16 * RL) void splitk_reduce_vec_kernel(const GemmPa
   }
 }
 
+
+// Split-K second pass that also applies the GroupNorm (+SiLU) which follows the product (GemmParams::gn_*): a block of 1024
+// threads owns one sample's HW <= 64 * RPT <= 256 rows x 64 columns (whole groups: 64 % (N / groups) == 0), thread (rl = t >> 4,
+// cg = t & 15) keeps the final fp32 values of rows rl + 64 j, columns 4 cg .. 4 cg + 3 in registers: partials summed in split
+// order, epilogue as in splitk_reduce_vec_kernel, column sums folded over the row lanes in a fixed order through LDS, group
+// statistics in double, then y = act(v * rstd * gamma + (beta - mean * rstd * gamma)) -> gn_out.  One launch instead of the
+// second pass + a GroupNorm launch (two or three at the 16x16 .. 4x4 levels, where every launch costs its latency).
+template <typename TC, int RPT>
+__global__ __launch_bounds__(1024) void splitk_reduce_gn_kernel(const GemmParams p, const int nsplit) {
+  __shared__ float red[64][16][8];
+  __shared__ float colsum[64][2];
+  __shared__ float scsh[64][2];
+  const int t = threadIdx.x, cg = t & 15, rl = t >> 4;
+  const int col = blockIdx.x * 64 + cg * 4;
+  const int HW = p.rows_per_batch;
+  const int b = blockIdx.y;
+  const long total = (long)p.M * p.N;
+  const int Wm = p.W;
+  f32x4_t v[RPT];
+  float4 bn = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias_n) bn = *(const float4*)(p.bias_n + col);
+  if (p.bias_bn) {
+    const float4 u = *(const float4*)(p.bias_bn + (long)b * p.ld_bn + col);
+    bn.x += u.x; bn.y += u.y; bn.z += u.z; bn.w += u.w;
+  }
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int r = rl + 64 * j;
+    v[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (r < HW) {
+      const int row = b * HW + r;
+      const float* src = (const float*)p.ws + (long)row * p.N + col;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      int k = 0;
+      for (; k + 4 <= nsplit; k += 4) {               // 4 partial loads in flight, added in split order
+        float4 w4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w4[q] = *(const float4*)(src + (long)(k + q) * total);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a.x += w4[q].x; a.y += w4[q].y; a.z += w4[q].z; a.w += w4[q].w; }
+      }
+      for (; k < nsplit; ++k) {
+        const float4 w1 = *(const float4*)(src + (long)k * total);
+        a.x += w1.x; a.y += w1.y; a.z += w1.z; a.w += w1.w;
+      }
+      a.x += bn.x; a.y += bn.y; a.z += bn.z; a.w += bn.w;
+      if (p.R) {
+        long rrow = row;
+        if (p.r_up) {
+          const int y = r / Wm, x = r - y * Wm;
+          rrow = ((long)b * (p.H >> 1) + (y >> 1)) * (Wm >> 1) + (x >> 1);
+        }
+        const float4 u = res_load4<TC>(p.R, rrow * p.ldr + col, p.r_lowp);
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+      }
+      a.x *= p.alpha; a.y *= p.alpha; a.z *= p.alpha; a.w *= p.alpha;
+      v[j] = f32x4_t{a.x, a.y, a.z, a.w};
+      cs[0] += a.x; cs[1] += a.y; cs[2] += a.z; cs[3] += a.w;
+      cq[0] += a.x * a.x; cq[1] += a.y * a.y; cq[2] += a.z * a.z; cq[3] += a.w * a.w;
+      if (p.C) {
+        if (p.c_f32) *(float4*)((float*)p.C + (long)row * p.ldc + col) = a;
+        else *(u32x2_t*)((TC*)p.C + (long)row * p.ldc + col) = (u32x2_t){pack2<TC>(a.x, a.y), pack2<TC>(a.z, a.w)};
+      }
+    }
+    if (p.col_stats && 64 * j < HW) {
+      // (uniform) the per-64-row-chunk column sums a later GroupNorm over this tensor reads (skip connections): chunk j of this
+      // sample is row j of every thread -- folded per chunk, in the layout of the GEMM epilogues
+      if (j) __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { red[rl][cg][2 * k] = v[j][k]; red[rl][cg][2 * k + 1] = v[j][k] * v[j][k]; }
+      __syncthreads();
+      if (t < 128) {
+        const int c2 = t >> 3, k2 = t & 7;
+        float o = red[0][c2][k2];
+        for (int r2 = 1; r2 < 64; ++r2) o += red[r2][c2][k2];
+        p.col_stats[((long)(b * (HW >> 6) + j) * p.N + blockIdx.x * 64 + c2 * 4) * 2 + k2] = o;
+      }
+    }
+  }
+  if (p.col_stats) __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[rl][cg][2 * k] = cs[k]; red[rl][cg][2 * k + 1] = cq[k]; }
+  __syncthreads();
+  if (t < 128) {                                      // (column group, value): row lanes folded in a fixed order
+    const int c2 = t >> 3, k2 = t & 7;
+    float o = red[0][c2][k2];
+    for (int r = 1; r < 64; ++r) o += red[r][c2][k2];
+    colsum[c2 * 4 + (k2 >> 1)][k2 & 1] = o;
+  }
+  __syncthreads();
+  if (t < 64) {
+    const int cpg = p.N / p.gn_groups;                 // channels per group: divides 64
+    const int g0 = (t / cpg) * cpg;
+    double s = 0, q = 0;
+    for (int k = 0; k < cpg; ++k) { s += (double)colsum[g0 + k][0]; q += (double)colsum[g0 + k][1]; }
+    const double n = (double)HW * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+    const int c = blockIdx.x * 64 + t;
+    const float sc = rstd * p.gn_gamma[c];
+    scsh[t][0] = sc;
+    scsh[t][1] = p.gn_beta[c] - (float)mean * sc;
+  }
+  __syncthreads();
+  float sc[4], sh[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { sc[k] = scsh[cg * 4 + k][0]; sh[k] = scsh[cg * 4 + k][1]; }
+  TC* out = (TC*)p.gn_out;
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int r = rl + 64 * j;
+    if (r < HW) {
+      float y0 = v[j][0] * sc[0] + sh[0], y1 = v[j][1] * sc[1] + sh[1], y2 = v[j][2] * sc[2] + sh[2], y3 = v[j][3] * sc[3] + sh[3];
+      if (p.gn_silu) {
+        y0 = y0 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(y0 * -1.44269504088896341f));
+        y1 = y1 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(y1 * -1.44269504088896341f));
+        y2 = y2 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(y2 * -1.44269504088896341f));
+        y3 = y3 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(y3 * -1.44269504088896341f));
+      }
+      *(u32x2_t*)(out + ((long)b * HW + r) * p.N + col) = (u32x2_t){pack2<TC>(y0, y1), pack2<TC>(y2, y3)};
+    }
+  }
+}
+
+static bool g_post_gn = true;     // plan switch 28
+void set_gemm_post_gn(bool on) { g_post_gn = on; }
 void set_gemm_splitk(bool on) { g_splitk = on; }
 
 void set_gemm_geom(int v) { g_dma_geom = v; }
@@ -2017,8 +2146,30 @@ static bool splitk_reduce_vec_ok(const GemmParams& p) {
 }
 
 
+// the second pass can apply a following GroupNorm: split-K launch whose samples are blocks of <= 256 rows, whole groups per
+// 64-column slab, no per-chunk column statistics wanted on top
+bool gemm_fuses_post_gn(const GemmParams& p, int groups) {
+  if (!g_post_gn || !dma_eligible(p) || p.nz0 * p.nz1 != 1 || p.dtype == DT_F32 || !dma_uses_splitk(p) || !splitk_reduce_vec_ok(p)) return false;
+  const int HW = p.rows_per_batch;
+  if (HW < 1 || HW > 256 || p.M % HW != 0 || p.bias_m || p.c_nchw || (p.col_stats && HW % 64 != 0)) return false;
+  if (p.r_up && (HW != p.H * p.W)) return false;
+  if (groups <= 0 || p.N % 64 != 0 || p.N % groups != 0 || 64 % (p.N / groups) != 0) return false;
+  return true;
+}
+
 template <typename TC>
 static int launch_splitk_reduce_t(const GemmParams& p, int nsplit, hipStream_t stream) {
+  if (p.gn_out) {
+    GemmParams q = p;
+    q.gn_out = nullptr; q.gn_gamma = q.gn_beta = nullptr;
+    T2P_REQUIRE(p.gn_gamma && p.gn_beta && gemm_fuses_post_gn(q, p.gn_groups), "post-GroupNorm second pass: ask gemm_fuses_post_gn first");
+    const int HW = p.rows_per_batch;
+    dim3 g(p.N / 64, p.M / HW);
+    if (HW <= 64) hipLaunchKernelGGL((splitk_reduce_gn_kernel<TC, 1>), g, dim3(1024), 0, stream, p, nsplit);
+    else hipLaunchKernelGGL((splitk_reduce_gn_kernel<TC, 4>), g, dim3(1024), 0, stream, p, nsplit);
+    T2P_HIP_CHECK(hipGetLastError());
+    return T2P_OK;
+  }
   if (splitk_reduce_vec_ok(p)) {
     // 64 x 64 output blocks when column statistics are wanted (their chunking), 16 x 64 otherwise
     const int rows = (p.col_stats || (long)p.M * p.N >= (1L << 22)) ? 64 : 16;
@@ -2320,7 +2471,12 @@ static int launch_thin_conv(const GemmParams& p, hipStream_t stream) {
 int launch_gemm(const GemmParams& p, hipStream_t stream) {
   const int vec = p.dtype == DT_F32 ? 4 : 8;
   const int Ctot = p.C0 + p.C1;
-  T2P_REQUIRE(p.A0 && p.Bw && p.C, "null operand");
+  T2P_REQUIRE(p.A0 && p.Bw && (p.C || p.gn_out), "null operand");
+  if (p.gn_out) {
+    GemmParams q = p;
+    q.gn_out = nullptr; q.gn_gamma = q.gn_beta = nullptr;
+    T2P_REQUIRE(p.gn_gamma && p.gn_beta && gemm_fuses_post_gn(q, p.gn_groups), "a following GroupNorm rides only on the split-K second pass (ask gemm_fuses_post_gn)");
+  }
   T2P_REQUIRE(p.M > 0 && p.N > 0 && Ctot > 0, "empty problem");
   T2P_REQUIRE(p.taps == 1 || p.taps == 9, "taps must be 1 or 9");
   T2P_REQUIRE(p.dtype != DT_F32 || p.a_f32, "fp32 compute takes fp32 sources");

@@ -1337,6 +1337,24 @@ int launch_convert(const float* in, void* out, int dtype, long n, hipStream_t s)
   return T2P_OK;
 }
 
+// compute dtype -> fp32 (development taps of the engine's intermediate maps)
+template <typename TI>
+__global__ __launch_bounds__(256) void widen_kernel(const TI* in, float* out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = to_f32(in[i]);
+}
+int launch_widen(const void* in, int dtype, float* out, long n, hipStream_t s) {
+  T2P_REQUIRE(in && out && n > 0, "widen arguments");
+  dim3 grid(ew_grid(n));
+  switch (dtype) {
+    case DT_F32: hipLaunchKernelGGL(widen_kernel<float>, grid, dim3(256), 0, s, (const float*)in, out, n); break;
+    case DT_BF16: hipLaunchKernelGGL(widen_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)in, out, n); break;
+    case DT_F16: hipLaunchKernelGGL(widen_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)in, out, n); break;
+    default: set_last_error("widen: bad dtype"); return T2P_ERR_INVALID;
+  }
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
 // out[b] = table[label_b]  (1 / sigma of the sample's time label; ncsnpp.py:223,259-261)
 __global__ void gather_label_kernel(const int* labels, const int* step_counter, const int* label_table, const float* table, float* out,
                                     int B, int N) {

@@ -141,6 +141,14 @@ struct GemmParams {
   float* col_stats = nullptr;  // optional [M/64][N][2]: per 64-row chunk column sum / sum of squares of C
   void* ws = nullptr;        // optional split-K workspace (fp32 partial tiles)
   size_t ws_bytes = 0;
+  // optional (ask gemm_fuses_post_gn): the GroupNorm (+SiLU) that FOLLOWS this product, applied by the split-K second pass,
+  // whose blocks then own whole (sample, 64-channel slab) pieces: gn_out [M][N] in the compute dtype receives
+  // act(GroupNorm(C)) computed from the fp32 values; C itself may then be null (the raw product is not wanted)
+  const float* gn_gamma = nullptr;
+  const float* gn_beta = nullptr;
+  int gn_groups = 0, gn_silu = 0;
+  float gn_eps = 1e-6f;
+  void* gn_out = nullptr;
 };
 
 int launch_gemm(const GemmParams& p, hipStream_t stream);
@@ -148,6 +156,8 @@ bool gemm_fuses_col_stats(const GemmParams& p);
 bool gemm_can_fuse_shortcut(const GemmParams& p);   // p without X0 / X1: would launch_gemm take the extra K segment?
 bool gemm_fuses_geglu(const GemmParams& p);
 bool gemm_fuses_col_stats_lowp(const GemmParams& p);
+bool gemm_fuses_post_gn(const GemmParams& p, int groups);   // p without gn_*: would launch_gemm apply a following GroupNorm of `groups` groups?
+void set_gemm_post_gn(bool on);
 void set_gemm_dma(bool on);
 void set_gemm_debug(int v);
 void set_gemm_geom(int v);

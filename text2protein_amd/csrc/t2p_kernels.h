@@ -117,6 +117,7 @@ int launch_attention_flash(int dtype, const void* q, long ldq, const void* k, lo
                            void* out, int B, int heads, int nq, int nk, int d, float scale, hipStream_t s, bool v_rowmajor = false);
 
 int launch_convert(const float* in, void* out, int dtype, long n, hipStream_t s);
+int launch_widen(const void* in, int dtype, float* out, long n, hipStream_t s);   // compute dtype -> fp32
 int launch_gather_label(const int* labels, const int* step_counter, const float* table, float* out, int B, int N,
                         hipStream_t s, const int* label_table = nullptr);
 int launch_apply_mask(float* x, const unsigned char* mask, const float* x_initial, long n, hipStream_t s);

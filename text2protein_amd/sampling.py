@@ -317,6 +317,16 @@ class PCStepper:
         """One PC step replayed from a captured hipGraph (device noise; needs a non-default stream)."""
         check(self.lib.t2p_sampler_step_graph(self._h, ptr(x), ptr(x_mean), stream_ptr()))
 
+    def count_dispatches(self, x, x_mean):
+        """Device dispatches one PC step enqueues (captured on a side stream and discarded; measurement only)."""
+        n = C.c_int(0)
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            check(self.lib.t2p_sampler_count_dispatches(self._h, ptr(x), ptr(x_mean), stream_ptr(), C.byref(n)))
+        torch.cuda.current_stream().wait_stream(side)
+        return int(n.value)
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):
