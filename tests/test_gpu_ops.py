@@ -613,3 +613,45 @@ def test_conv3x3_followed_by_groupnorm_in_the_second_pass(lib):
                                             1, 8, 8, 64, 64, None) != 0
     finally:
         lib.t2p_debug_set(10, 0)
+
+
+@pytest.mark.parametrize("dt", [2, 1])
+@pytest.mark.parametrize("B,n,d", [(3, 16, 256), (2, 64, 512), (2, 256, 256), (2, 256, 512), (1, 1024, 512), (2, 1024, 256), (1, 512, 1024),
+                                   (2, 64, 1024), (2, 40, 512), (1, 200, 256), (1, 520, 512), (1, 8, 256)])
+def test_wide_head_attention_in_one_launch(lib, dt, B, n, d):
+    """AttnBlockpp's attention (layers.py:160-176: ONE head, d = C, all h w pixels as keys): attn_strip_kernel against torch fp64
+    on the rounded operands, scores of realistic spread (|s| up to ~10 after scaling), NaN in the padding columns of V^T, and
+    against the unfused GEMM -> softmax -> GEMM path (plan switch 29) on the same inputs."""
+    g = torch.Generator().manual_seed(n * 7 + d)
+    td = TDT[dt]
+    q = torch.randn(B, n, d, generator=g) * 1.7
+    k = torch.randn(B, n, d, generator=g) * 1.7
+    v = torch.randn(B, n, d, generator=g)
+    scale = d ** -0.5
+    qr, kr, vr = (t.to(td).double() for t in (q, k, v))
+    ref = torch.softmax(qr @ kr.transpose(-1, -2) * scale, dim=-1) @ vr
+    npad = (n + 7) // 8 * 8 + 8                                   # a row stride larger than n: the columns beyond n must never be read
+    vt = torch.full((B, d, npad), float("nan"))
+    vt[:, :, :n] = v.transpose(1, 2)
+    # q | k interleaved the way the engine holds them: one [rows][2 d] buffer
+    qk = torch.cat([q, k], -1).to(td)
+    dqk = dev(qk)
+    ws = torch.empty(lib.t2p_op_attention_ws(dt, B, 1, n, n), dtype=torch.uint8, device="cuda")
+    outs = {}
+    try:
+        for sw in (1, 0):
+            check(lib, lib.t2p_debug_set(29, sw))
+            out = torch.full((B, n, d), float("nan"), device="cuda", dtype=td)
+            vt_in = vt.clone()
+            if sw == 0:
+                vt_in[:, :, n:] = 0.0                             # the unfused path multiplies the (zero) padding probabilities
+            check(lib, lib.t2p_op_attention(dt, P(dqk), 2 * d, C.c_void_p(dqk.data_ptr() + d * dqk.element_size()), 2 * d,
+                                            P(dev(vt_in.to(td))), npad, P(out), B, 1, n, n, d, scale, P(ws), None))
+            torch.cuda.synchronize()
+            outs[sw] = out.float().cpu()
+    finally:
+        lib.t2p_debug_set(29, 1)
+    tol = 8e-3 if dt == 1 else 1e-3
+    e1, e0 = rel_l2(outs[1], ref), rel_l2(outs[0], ref)
+    assert torch.isfinite(outs[1]).all() and e1 < tol, (dt, B, n, d, e1, e0)
+    assert e1 < 1.5 * e0 + 1e-4, (e1, e0)                          # not less accurate than the unfused path

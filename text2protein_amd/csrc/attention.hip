@@ -272,6 +272,319 @@ static int launch_flash_t(const FlashArgs& a, int B, int heads, hipStream_t s) {
   return T2P_OK;
 }
 
+
+// =================================================================================================
+// Single-head attention with a WIDE head (AttnBlockpp.forward, reference score_sde_pytorch/models/layers.py:160-176:
+// one head, d = C = 256 / 512 / 1024, n = h w <= 1024 pixels): softmax(q k^T / sqrt C) v in ONE launch, the score
+// strip never leaves the chip.
+//
+// A d = 512 flash kernel would need 32 queries x 512 channels of output accumulators per wavefront (256 registers), so
+// the work is cut the other way.  One workgroup (8 wavefronts) owns a strip of 64 queries and ALL n <= 1024 keys:
+//   pass 1  wavefront w computes S^T for its n / 8 keys x 64 queries over the whole head dimension (the strip of scores is
+//           64 x 1024 fp32 = 256 KiB = the accumulators of 8 wavefronts x 128 registers); the 64 x d query strip sits in
+//           LDS (shared by all wavefronts), the key rows stream from global memory straight into MFMA A fragments -- each
+//           wavefront reads keys nobody else in the workgroup reads, so LDS staging would buy nothing -- with the head
+//           dimension permuted so that a lane reads 32 contiguous bytes per 32-deep step (both operands use the same order);
+//   softmax exact (not online): per-query maximum and sum exchanged between the wavefronts through LDS (two barriers),
+//           P = exp2(...) unnormalised in the compute dtype written over the dead query strip, [query][key];
+//   pass 2  wavefront w owns d / 8 output channels for all 64 queries: O^T = V^T P^T with V^T rows (the engine's transposed
+//           value projection) streaming from global memory into A fragments and P^T fragments read from LDS;
+//           O is scaled by 1 / sum and stored [query][channel].
+// Orientation as in the flash kernel above: the query sits on the lane (S^T = K Q^T, O^T = V^T P^T), so the softmax
+// statistics are per-lane scalars and one xor-32 shuffle.  Launch count of an AttnBlockpp: 7 -> 5, no fp32 score tensor and
+// no probability tensor in HBM (2 x 134 MB + 67 MB per launch at the 32 x 32 level of cfg2).
+struct StripArgs {
+  const void* q; long ldq; long sq_b;       // [B][n][ldq]
+  const void* k; long ldk; long sk_b;       // [B][n][ldk]
+  const void* vt; long ldvt; long svt_b;    // [B][D][ldvt]  (V^T, ldvt >= n rounded up to 8)
+  void* out; long ldo; long so_b;           // [B][n][ldo]
+  int n;
+  float scale_log2e;
+};
+
+template <typename TC, int D, int NKT>      // NKT: 32-key tiles per wavefront (n <= 256 NKT)
+__global__ __launch_bounds__(512) void attn_strip_kernel(const StripArgs a) {
+  constexpr int QRS = D * 2 + 16;            // query strip row stride (bytes): consecutive rows 4 banks apart
+  constexpr int KW = NKT * 32;               // keys per wavefront
+  constexpr int PRS = KW * 8 * 2 + 16;       // probability strip row stride (bytes)
+  constexpr int CT = D / 256;                // 32-channel tiles of O^T per wavefront
+  constexpr int REGION = (64 * QRS > 64 * PRS) ? 64 * QRS : 64 * PRS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* st_max = (float*)(smem + REGION);   // [8][64]
+  float* st_sum = st_max + 8 * 64;           // [8][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.y, q0 = blockIdx.x * 64, n = a.n;
+  const TC* Q = (const TC*)a.q + (long)b * a.sq_b;
+  const TC* K = (const TC*)a.k + (long)b * a.sk_b;
+  const TC* VT = (const TC*)a.vt + (long)b * a.svt_b;
+
+  // ---- query strip -> LDS (rows beyond n: zeros) ----------------------------------------------------------------
+  for (int i = tid; i < 64 * (D / 8); i += 512) {
+    const int row = i / (D / 8), ch = i - row * (D / 8);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (q0 + row < n) v = *(const uint4*)(Q + (long)(q0 + row) * a.ldq + ch * 8);
+    *(uint4*)(smem + row * QRS + ch * 16) = v;
+  }
+  __syncthreads();
+
+  // ---- pass 1: S^T (this wavefront's keys x 64 queries) ---------------------------------------------------------------
+  const int key_w = wave * KW;                                   // first key of this wavefront
+  const bool w_active = key_w < n;                               // wave-uniform
+  f32x16 sacc[NKT][2];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) sacc[kt][qt][v] = 0.f;
+  if (w_active) {
+    // lane (key lr, half lh) of key tile kt reads K[key][32 S + 16 lh .. + 15]: the fragments of the two 16-deep MFMA steps of
+    // super-step S (keys beyond n: clamped to a valid row, their scores are masked below)
+    const TC* krow[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      int key = key_w + kt * 32 + lr;
+      key = key < n ? key : n - 1;
+      krow[kt] = K + (long)key * a.ldk + 16 * lh;
+    }
+    const unsigned char* qb0 = smem + lr * QRS + 32 * lh;        // query tile 0; tile 1 is 32 rows further
+    uint4 ka0[NKT][2], ka1[NKT][2];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      ka0[kt][0] = *(const uint4*)(krow[kt]);
+      ka0[kt][1] = *(const uint4*)(krow[kt] + 8);
+    }
+    auto sstep = [&](const uint4 (&ka)[NKT][2], int S) {
+      uint4 qf[2][2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) qf[qt][j] = *(const uint4*)(qb0 + qt * 32 * QRS + S * 64 + j * 16);
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) AMma<TC>::run(ka[kt][j], qf[qt][j], sacc[kt][qt]);
+    };
+    for (int S = 0; S < D / 32; S += 2) {                          // D / 32 is even
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        ka1[kt][0] = *(const uint4*)(krow[kt] + 32 * (S + 1));
+        ka1[kt][1] = *(const uint4*)(krow[kt] + 32 * (S + 1) + 8);
+      }
+      sstep(ka0, S);
+      if (S + 2 < D / 32) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          ka0[kt][0] = *(const uint4*)(krow[kt] + 32 * (S + 2));
+          ka0[kt][1] = *(const uint4*)(krow[kt] + 32 * (S + 2) + 8);
+        }
+      }
+      sstep(ka1, S + 1);
+    }
+  }
+
+  // ---- exact softmax over all keys: this lane = query (32 qt + lr), registers = keys (v & 3) + 8 (v >> 2) + 4 lh of a tile -------------
+  float mloc[2] = {-INFINITY, -INFINITY};
+  if (w_active) {
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int kbase = key_w + kt * 32;
+      if (kbase + 32 > n) {                                      // wave-uniform: ragged or empty tile
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+          if (kbase + (v & 3) + 8 * (v >> 2) + 4 * lh >= n) { sacc[kt][0][v] = -INFINITY; sacc[kt][1][v] = -INFINITY; }
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) mloc[qt] = fmaxf(mloc[qt], sacc[kt][qt][v]);
+    }
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    mloc[qt] = fmaxf(mloc[qt], __shfl_xor(mloc[qt], 32, 64));
+    if (lh == 0) st_max[wave * 64 + qt * 32 + lr] = mloc[qt];
+  }
+  __syncthreads();                    // every wavefront is also done with the query strip: the region becomes the P strip
+  float mq[2], lsum[2] = {0.f, 0.f};
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float m = st_max[qt * 32 + lr];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fmaxf(m, st_max[w * 64 + qt * 32 + lr]);
+    mq[qt] = m * a.scale_log2e;        // finite: key 0 exists (scale > 0: the maximum commutes with the scaling)
+  }
+  if (w_active) {
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        unsigned char* prow = smem + (qt * 32 + lr) * PRS + (key_w + kt * 32 + 4 * lh) * 2;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float e[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            e[i] = __builtin_amdgcn_exp2f(fmaf(sacc[kt][qt][4 * g + i], a.scale_log2e, -mq[qt]));   // exp2(-inf) = 0 for masked keys
+            lsum[qt] += e[i];
+          }
+          *(uint2*)(prow + 16 * g) = make_uint2(pack2<TC>(e[0], e[1]), pack2<TC>(e[2], e[3]));     // keys 8 g + 4 lh + 0..3 of the tile
+        }
+      }
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    lsum[qt] += __shfl_xor(lsum[qt], 32, 64);
+    if (lh == 0) st_sum[wave * 64 + qt * 32 + lr] = lsum[qt];
+  }
+  __syncthreads();
+  float inv[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = st_sum[qt * 32 + lr];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) l += st_sum[w * 64 + qt * 32 + lr];
+    inv[qt] = 1.f / l;
+  }
+
+  // ---- pass 2: O^T (this wavefront's d / 8 channels x 64 queries) = V^T P^T over all keys -------------------------------------------
+  f32x16 oacc[CT][2];
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) oacc[t][qt][v] = 0.f;
+  const int ch_w = wave * (D / 8);
+  const TC* vrow[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) vrow[t] = VT + (long)(ch_w + t * 32 + lr) * a.ldvt + 16 * lh;
+  const int nss = (n + 31) >> 5;                                 // 32-key super-steps
+  // V^T fragment of super-step S, step j: keys 32 S + 16 lh + 8 j .. + 7 (whole 8-key chunks are in or out: n % 8 == 0)
+  auto vload = [&](int t, int S, int j) -> uint4 {
+    const int key = 32 * S + 16 * lh + 8 * j;
+    return key < n ? *(const uint4*)(vrow[t] + 32 * S + 8 * j) : make_uint4(0, 0, 0, 0);
+  };
+  uint4 va0[CT][2], va1[CT][2];                                  // two named buffers (a runtime-indexed one would live in scratch)
+#pragma unroll
+  for (int t = 0; t < CT; ++t) { va0[t][0] = vload(t, 0, 0); va0[t][1] = vload(t, 0, 1); }
+  const unsigned char* pb0 = smem + lr * PRS + 32 * lh;
+  auto pstep = [&](const uint4 (&va)[CT][2], int S) {
+    uint4 pf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) pf[qt][j] = *(const uint4*)(pb0 + qt * 32 * PRS + S * 64 + j * 16);
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) AMma<TC>::run(va[t][j], pf[qt][j], oacc[t][qt]);
+  };
+  for (int S = 0; S < nss; S += 2) {
+    if (S + 1 < nss) {
+#pragma unroll
+      for (int t = 0; t < CT; ++t) { va1[t][0] = vload(t, S + 1, 0); va1[t][1] = vload(t, S + 1, 1); }
+    }
+    pstep(va0, S);
+    if (S + 1 < nss) {
+      if (S + 2 < nss) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t) { va0[t][0] = vload(t, S + 2, 0); va0[t][1] = vload(t, S + 2, 1); }
+      }
+      pstep(va1, S + 1);
+    }
+  }
+
+  // ---- O[q][channel] = O^T / l ---------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qrow = q0 + qt * 32 + lr;
+    if (qrow < n) {
+      TC* orow = (TC*)a.out + (long)b * a.so_b + (long)qrow * a.ldo + ch_w;
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 u;
+          u.x = pack2<TC>(oacc[t][qt][4 * g + 0] * inv[qt], oacc[t][qt][4 * g + 1] * inv[qt]);
+          u.y = pack2<TC>(oacc[t][qt][4 * g + 2] * inv[qt], oacc[t][qt][4 * g + 3] * inv[qt]);
+          *(uint2*)(orow + t * 32 + 8 * g + 4 * lh) = u;
+        }
+    }
+  }
+}
+
+bool g_attn_strip = true;       // plan switch 29
+bool attention_strip_eligible(int dtype, int heads, int nq, int nk, int d, long ldq, long ldk, long ldvt, long ldo) {
+  if (!g_attn_strip || dtype == DT_F32 || heads != 1 || nq != nk) return false;
+  if (d != 256 && d != 512 && d != 1024) return false;
+  if (nk < 8 || nk > 1024 || nk % 8 != 0) return false;
+  if (d == 1024 && nk > 512) return false;             // 64 x 1024 query strip + 64 x 1024 probability strip: beyond the LDS budget
+  return ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldvt >= nk && ldo % 4 == 0;
+}
+
+template <typename TC, int D, int NKT>
+static int launch_strip_t(const StripArgs& a, int B, hipStream_t s) {
+  constexpr int QB = 64 * (D * 2 + 16), PB = 64 * (NKT * 32 * 8 * 2 + 16);
+  constexpr int smem = (QB > PB ? QB : PB) + 2 * 8 * 64 * 4;
+  static_assert(smem <= 160 * 1024, "attn_strip: LDS budget");
+  auto kern = attn_strip_kernel<TC, D, NKT>;
+  T2P_TRY(ensure_dynamic_lds((const void*)kern, smem));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (prof_on()) {
+    T2P_HIP_CHECK(hipEventCreate(&e0));
+    T2P_HIP_CHECK(hipEventCreate(&e1));
+    T2P_HIP_CHECK(hipEventRecord(e0, s));
+  }
+  hipLaunchKernelGGL(kern, dim3((a.n + 63) / 64, B), dim3(512), smem, s, a);
+  if (e0) {
+    T2P_HIP_CHECK(hipEventRecord(e1, s));
+    prof_attention(e0, e1, 4.0 * (double)a.n * a.n * D * B);
+  }
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+int launch_attention_strip(int dtype, const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
+                           int B, int n, int d, float scale, hipStream_t s) {
+  T2P_REQUIRE(attention_strip_eligible(dtype, 1, n, n, d, ldq, ldk, ldvt, ldo), "wide-head attention: unsupported shape");
+  T2P_REQUIRE(q && k && vt && out && B > 0 && scale > 0.f, "wide-head attention arguments");
+  T2P_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 8) == 0,
+              "wide-head attention: operands must be 16-byte aligned");
+  StripArgs a;
+  a.q = q; a.ldq = ldq; a.sq_b = (long)n * ldq;
+  a.k = k; a.ldk = ldk; a.sk_b = (long)n * ldk;
+  a.vt = vt; a.ldvt = ldvt; a.svt_b = (long)d * ldvt;
+  a.out = out; a.ldo = ldo; a.so_b = (long)n * ldo;
+  a.n = n;
+  a.scale_log2e = scale * 1.44269504088896340736f;
+  const int nkt = n <= 256 ? 1 : (n <= 512 ? 2 : 4);
+#define T2P_STRIP(TC, DD)                                                        \
+  do {                                                                           \
+    if (nkt == 1) return launch_strip_t<TC, DD, 1>(a, B, s);                     \
+    if (nkt == 2) return launch_strip_t<TC, DD, 2>(a, B, s);                     \
+    if constexpr (DD != 1024) return launch_strip_t<TC, DD, 4>(a, B, s);         \
+  } while (0)
+  if (dtype == DT_BF16) {
+    if (d == 256) T2P_STRIP(bf16_t, 256);
+    if (d == 512) T2P_STRIP(bf16_t, 512);
+    if (d == 1024) T2P_STRIP(bf16_t, 1024);
+  } else {
+    if (d == 256) T2P_STRIP(f16_t, 256);
+    if (d == 512) T2P_STRIP(f16_t, 512);
+    if (d == 1024) T2P_STRIP(f16_t, 1024);
+  }
+#undef T2P_STRIP
+  set_last_error("wide-head attention: no instantiation");
+  return T2P_ERR_INVALID;
+}
+
 bool attention_flash_eligible(int dtype, int d, long ldq, long ldk, long ldvt, long ldo) {
   if (dtype == DT_F32) return false;
   if (d != 32 && d != 64 && d != 128) return false;

@@ -338,6 +338,8 @@ int t2p_op_attention(int dtype, const void* q, int64_t ldq, const void* k, int64
   hipStream_t s = (hipStream_t)stream;
   if (g_flash_attention && attention_flash_eligible(dtype, d, ldq, ldk, ldvt, (long)heads * d))
     return launch_attention_flash(dtype, q, ldq, k, ldk, vt, ldvt, out, batch, heads, nq, nk, d, scale, s);
+  if (attention_strip_eligible(dtype, heads, nq, nk, d, ldq, ldk, ldvt, d))
+    return launch_attention_strip(dtype, q, ldq, k, ldk, vt, ldvt, out, d, batch, nq, d, scale, s);
   const long nkp = rup8(nk), rows = (long)batch * heads * nq;
   float* S = (float*)workspace;
   void* P = (char*)workspace + ((rows * nkp * 4 + 255) / 256) * 256;
@@ -467,6 +469,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 26) { t2p::g_pre_conv_mfma = value != 0; return T2P_OK; }
   if (key == 27) { t2p::g_gn_apply_cols = value != 0; return T2P_OK; }
   if (key == 28) { set_gemm_post_gn(value != 0); return T2P_OK; }
+  if (key == 29) { t2p::g_attn_strip = value != 0; return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) {
 #ifndef T2P_ABLATION

@@ -879,6 +879,8 @@ int Engine::attention(const void* q, long ldq, const void* k, long ldk, const vo
   const int dt = dtype();
   if (g_flash_attention && attention_flash_eligible(dt, d, ldq, ldk, ldvt, (long)heads * d))
     return launch_attention_flash(dt, q, ldq, k, ldk, vt, ldvt, out, B, heads, nq, nk, d, scale, s);
+  if (attention_strip_eligible(dt, heads, nq, nk, d, ldq, ldk, ldvt, d))
+    return launch_attention_strip(dt, q, ldq, k, ldk, vt, ldvt, out, d, B, nq, d, scale, s);
   const long nkp = (long)round_up((size_t)nk, 8);
   const long rows = (long)B * heads * nq;
   POOL_GET(S, float*, (size_t)rows * nkp * 4);

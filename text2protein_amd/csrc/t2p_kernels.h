@@ -116,6 +116,12 @@ bool attention_flash_eligible(int dtype, int d, long ldq, long ldk, long ldvt, l
 int launch_attention_flash(int dtype, const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt,
                            void* out, int B, int heads, int nq, int nk, int d, float scale, hipStream_t s, bool v_rowmajor = false);
 
+// ---- single-head attention with a wide head (AttnBlockpp, layers.py:160-176): d = 256 / 512 / 1024, n <= 1024, one launch --------
+extern bool g_attn_strip;
+bool attention_strip_eligible(int dtype, int heads, int nq, int nk, int d, long ldq, long ldk, long ldvt, long ldo);
+int launch_attention_strip(int dtype, const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
+                           int B, int n, int d, float scale, hipStream_t s);
+
 int launch_convert(const float* in, void* out, int dtype, long n, hipStream_t s);
 int launch_widen(const void* in, int dtype, float* out, long n, hipStream_t s);   // compute dtype -> fp32
 int launch_gather_label(const int* labels, const int* step_counter, const float* table, float* out, int B, int N,
