@@ -192,6 +192,15 @@ int64_t t2p_op_attention_ws(int dtype, int batch, int heads, int nq, int nk);
 int t2p_op_attention(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt,
                      int64_t ldvt, void* out, int batch, int heads, int nq, int nk, int d, float scale,
                      void* workspace, void* stream);
+/* AttnBlockpp.forward after its projections (layers.py:168-176: w = softmax(q k^T / sqrt C) over ALL h w pixels, ONE head of
+ * width d = C; h = w v; (x + NIN_3(h)) / sqrt 2) in one launch: q, k [batch][n][ld*] and vt = v^T [batch][d][ldvt] in the 16-bit
+ * compute dtype -- the engine folds NIN_3 into the value projection (rows of w sum to 1), so what remains of the block's tail is
+ * out[batch][n][d] = alpha (w v + bias[d] + residual[batch][n][d]), stored fp32 (out_f32) or in the compute dtype; col_stats
+ * (optional, n % 64 == 0): [batch n / 64][d][2] column sums / sums of squares of out's fp32 values per 64 queries (the next
+ * GroupNorm's input).  d = 256 / 512 / 1024, n <= 1024 (<= 512 at d = 1024), n % 8 == 0. */
+int t2p_op_attention_wide(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* out,
+                          int out_f32, const float* bias, const void* residual, int residual_16bit, float alpha, float* col_stats,
+                          int batch, int n, int d, float scale, void* stream);
 /* self-attention on the output of ONE stacked projection (CrossAttention.forward with context = x, model/attention.py:
  * 170-191): qkv [batch][n][ld] holds q | k | v in three column blocks of heads*d (head h at column h*d of its block);
  * out [batch][n][heads*d].  V is read row-major -- the fused kernel transposes it on the way out of LDS -- so no

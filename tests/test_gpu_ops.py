@@ -655,3 +655,39 @@ def test_wide_head_attention_in_one_launch(lib, dt, B, n, d):
     e1, e0 = rel_l2(outs[1], ref), rel_l2(outs[0], ref)
     assert torch.isfinite(outs[1]).all() and e1 < tol, (dt, B, n, d, e1, e0)
     assert e1 < 1.5 * e0 + 1e-4, (e1, e0)                          # not less accurate than the unfused path
+
+
+@pytest.mark.parametrize("dt", [2, 1])
+@pytest.mark.parametrize("B,n,d,r16,out_f32", [(2, 64, 256, 1, 0), (2, 256, 512, 1, 0), (1, 1024, 512, 1, 0), (2, 16, 512, 0, 1), (1, 256, 1024, 0, 1),
+                                               (3, 64, 512, 1, 1)])
+def test_wide_head_attention_with_the_block_tail(lib, dt, B, n, d, r16, out_f32):
+    """t2p_op_attention_wide: attention of AttnBlockpp plus what is left of the block's tail once NIN_3 is folded into the value
+    projection -- alpha (w v + bias + residual) -- and the per-64-query column statistics of the result, against torch fp64."""
+    g = torch.Generator().manual_seed(n + d + r16)
+    td = TDT[dt]
+    q, k = torch.randn(B, n, d, generator=g) * 1.5, torch.randn(B, n, d, generator=g) * 1.5
+    v = torch.randn(B, n, d, generator=g)
+    bias = torch.randn(d, generator=g)
+    res = torch.randn(B, n, d, generator=g) * 2
+    res_in = res.to(td) if r16 else res
+    scale, alpha = d ** -0.5, 0.5 ** 0.5
+    qr, kr, vr = (t.to(td).double() for t in (q, k, v))
+    ref = (torch.softmax(qr @ kr.transpose(-1, -2) * scale, dim=-1) @ vr + bias.double() + res_in.double()) * alpha
+    npad = (n + 7) // 8 * 8
+    vt = v.transpose(1, 2).contiguous()
+    out = torch.full((B, n, d), float("nan"), device="cuda", dtype=torch.float32 if out_f32 else td)
+    want_cs = n % 64 == 0
+    cs = torch.full((B * n // 64, d, 2), float("nan"), device="cuda") if want_cs else None
+    check(lib, lib.t2p_op_attention_wide(dt, P(dev(q.to(td))), d, P(dev(k.to(td))), d, P(dev(vt.to(td))), npad, P(out), out_f32, P(dev(bias)),
+                                         P(dev(res_in)), r16, alpha, P(cs) if want_cs else None, B, n, d, scale, None))
+    torch.cuda.synchronize()
+    e = rel_l2(out.float().cpu(), ref)
+    assert e < (8e-3 if dt == 1 else 1e-3), e
+    if want_cs:
+        # the statistics are those of the fp32 values the kernel held (before rounding to 16 bits): compare with the reference's
+        r64 = ref.reshape(B * n // 64, 64, d)
+        ref_cs = torch.stack([r64.sum(1), (r64 * r64).sum(1)], -1)
+        assert rel_l2(cs.cpu(), ref_cs) < (8e-3 if dt == 1 else 1e-3)
+        if out_f32:                                   # and exactly consistent with the stored fp32 output
+            o64 = out.cpu().double().reshape(B * n // 64, 64, d)
+            assert rel_l2(cs.cpu(), torch.stack([o64.sum(1), (o64 * o64).sum(1)], -1)) < 1e-5

@@ -300,6 +300,13 @@ struct StripArgs {
   void* out; long ldo; long so_b;           // [B][n][ldo]
   int n;
   float scale_log2e;
+  // optional epilogue (ep != 0): out = alpha (attention + bias[channel] + residual[query][channel]) in fp32 or the compute dtype,
+  // col_stats [B n / 64][D][2] = column sum / sum of squares of those fp32 values over the strip's 64 queries
+  int ep, out_f32, r_lowp;
+  const float* bias;
+  const void* res; long ldr;
+  float alpha;
+  float* col_stats;
 };
 
 template <typename TC, int D, int NKT>      // NKT: 32-key tiles per wavefront (n <= 256 NKT)
@@ -501,23 +508,72 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(const StripArgs a) {
     }
   }
 
-  // ---- O[q][channel] = O^T / l ---------------------------------------------------------------------------------------------------
+  // ---- O[q][channel] = O^T / l (+ epilogue) -----------------------------------------------------------------------------------------
+  if (!a.ep) {
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    const int qrow = q0 + qt * 32 + lr;
-    if (qrow < n) {
-      TC* orow = (TC*)a.out + (long)b * a.so_b + (long)qrow * a.ldo + ch_w;
+    for (int qt = 0; qt < 2; ++qt) {
+      const int qrow = q0 + qt * 32 + lr;
+      if (qrow < n) {
+        TC* orow = (TC*)a.out + (long)b * a.so_b + (long)qrow * a.ldo + ch_w;
 #pragma unroll
-      for (int t = 0; t < CT; ++t)
+        for (int t = 0; t < CT; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          uint2 u;
-          u.x = pack2<TC>(oacc[t][qt][4 * g + 0] * inv[qt], oacc[t][qt][4 * g + 1] * inv[qt]);
-          u.y = pack2<TC>(oacc[t][qt][4 * g + 2] * inv[qt], oacc[t][qt][4 * g + 3] * inv[qt]);
-          *(uint2*)(orow + t * 32 + 8 * g + 4 * lh) = u;
-        }
+          for (int g = 0; g < 4; ++g) {
+            uint2 u;
+            u.x = pack2<TC>(oacc[t][qt][4 * g + 0] * inv[qt], oacc[t][qt][4 * g + 1] * inv[qt]);
+            u.y = pack2<TC>(oacc[t][qt][4 * g + 2] * inv[qt], oacc[t][qt][4 * g + 3] * inv[qt]);
+            *(uint2*)(orow + t * 32 + 8 * g + 4 * lh) = u;
+          }
+      }
     }
+    return;
   }
+  // the block's closing arithmetic here instead of in an output-projection GEMM (the projection itself is folded into V):
+  // alpha (O + bias + residual), and the column statistics the next GroupNorm reads, over this strip's 64 queries
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ch = ch_w + t * 32 + 8 * g + 4 * lh;
+      const float4 bs = a.bias ? *(const float4*)(a.bias + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const int qrow = q0 + qt * 32 + lr;
+        if (qrow < n) {
+          const long ro = (long)b * n * a.ldr + (long)qrow * a.ldr + ch;
+          float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+          if (a.res) {
+            if (a.r_lowp) {
+              union { uint2 u; TC e[4]; } x;
+              x.u = *(const uint2*)((const TC*)a.res + ro);
+              r0 = to_f32(x.e[0]); r1 = to_f32(x.e[1]); r2 = to_f32(x.e[2]); r3 = to_f32(x.e[3]);
+            } else {
+              const float4 x = *(const float4*)((const float*)a.res + ro);
+              r0 = x.x; r1 = x.y; r2 = x.z; r3 = x.w;
+            }
+          }
+          const float v0 = (oacc[t][qt][4 * g + 0] * inv[qt] + bs.x + r0) * a.alpha, v1 = (oacc[t][qt][4 * g + 1] * inv[qt] + bs.y + r1) * a.alpha;
+          const float v2 = (oacc[t][qt][4 * g + 2] * inv[qt] + bs.z + r2) * a.alpha, v3 = (oacc[t][qt][4 * g + 3] * inv[qt] + bs.w + r3) * a.alpha;
+          cs[0] += v0; cs[1] += v1; cs[2] += v2; cs[3] += v3;
+          cq[0] += v0 * v0; cq[1] += v1 * v1; cq[2] += v2 * v2; cq[3] += v3 * v3;
+          const long oo = (long)b * a.so_b + (long)qrow * a.ldo + ch;
+          if (a.out_f32) *(float4*)((float*)a.out + oo) = make_float4(v0, v1, v2, v3);
+          else *(uint2*)((TC*)a.out + oo) = make_uint2(pack2<TC>(v0, v1), pack2<TC>(v2, v3));
+        }
+      }
+      if (a.col_stats) {                              // (uniform) sum over the 32 query lanes of this half, fixed butterfly order
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int sh = 1; sh < 32; sh <<= 1) { cs[i] += __shfl_xor(cs[i], sh, 64); cq[i] += __shfl_xor(cq[i], sh, 64); }
+        if (lr == 0) {
+          float* dst = a.col_stats + ((long)(b * (n >> 6) + blockIdx.x) * D + ch) * 2;
+          *(float4*)dst = make_float4(cs[0], cq[0], cs[1], cq[1]);
+          *(float4*)(dst + 4) = make_float4(cs[2], cq[2], cs[3], cq[3]);
+        }
+      }
+    }
 }
 
 bool g_attn_strip = true;       // plan switch 29
@@ -552,7 +608,7 @@ static int launch_strip_t(const StripArgs& a, int B, hipStream_t s) {
 }
 
 int launch_attention_strip(int dtype, const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
-                           int B, int n, int d, float scale, hipStream_t s) {
+                           int B, int n, int d, float scale, hipStream_t s, const StripEpilogue* ep) {
   T2P_REQUIRE(attention_strip_eligible(dtype, 1, n, n, d, ldq, ldk, ldvt, ldo), "wide-head attention: unsupported shape");
   T2P_REQUIRE(q && k && vt && out && B > 0 && scale > 0.f, "wide-head attention arguments");
   T2P_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 8) == 0,
@@ -564,6 +620,14 @@ int launch_attention_strip(int dtype, const void* q, long ldq, const void* k, lo
   a.out = out; a.ldo = ldo; a.so_b = (long)n * ldo;
   a.n = n;
   a.scale_log2e = scale * 1.44269504088896340736f;
+  a.ep = ep ? 1 : 0; a.out_f32 = 0; a.r_lowp = 0; a.bias = nullptr; a.res = nullptr; a.ldr = 0; a.alpha = 1.f; a.col_stats = nullptr;
+  if (ep) {
+    T2P_REQUIRE(!ep->col_stats || n % 64 == 0, "wide-head attention: column statistics need whole 64-query strips");
+    T2P_REQUIRE(!ep->residual || (ep->ldr % 4 == 0 && ((uintptr_t)ep->residual % 16) == 0), "wide-head attention: residual alignment");
+    T2P_REQUIRE(((uintptr_t)out % 16) == 0 && ldo % 4 == 0, "wide-head attention: output alignment");
+    a.out_f32 = ep->out_f32; a.r_lowp = ep->r_lowp; a.bias = ep->bias; a.res = ep->residual; a.ldr = ep->ldr; a.alpha = ep->alpha;
+    a.col_stats = ep->col_stats;
+  }
   const int nkt = n <= 256 ? 1 : (n <= 512 ? 2 : 4);
 #define T2P_STRIP(TC, DD)                                                        \
   do {                                                                           \

@@ -361,6 +361,17 @@ int t2p_op_attention(int dtype, const void* q, int64_t ldq, const void* k, int64
   API_END
 }
 
+int t2p_op_attention_wide(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* out,
+                          int out_f32, const float* bias, const void* residual, int residual_16bit, float alpha, float* col_stats,
+                          int batch, int n, int d, float scale, void* stream) {
+  API_BEGIN
+  T2P_REQUIRE(attention_strip_eligible(dtype, 1, n, n, d, ldq, ldk, ldvt, d), "attention_wide: 16-bit dtypes, d = 256 / 512 / 1024, n <= 1024 (512 at d = 1024), n % 8 == 0");
+  StripEpilogue ep;
+  ep.bias = bias; ep.residual = residual; ep.r_lowp = residual_16bit; ep.ldr = d; ep.alpha = alpha; ep.out_f32 = out_f32; ep.col_stats = col_stats;
+  return launch_attention_strip(dtype, q, ldq, k, ldk, vt, ldvt, out, d, batch, n, d, scale, (hipStream_t)stream, &ep);
+  API_END
+}
+
 int t2p_op_attention_qkv(int dtype, const void* qkv, int64_t ld, void* out, int batch, int heads, int n, int d, float scale, void* stream) {
   API_BEGIN
   const long C = (long)heads * d;
@@ -470,6 +481,10 @@ int t2p_debug_set(int key, int value) {
   if (key == 27) { t2p::g_gn_apply_cols = value != 0; return T2P_OK; }
   if (key == 28) { set_gemm_post_gn(value != 0); return T2P_OK; }
   if (key == 29) { t2p::g_attn_strip = value != 0; return T2P_OK; }
+  if (key == 32) { g_attn_merged = value != 0; return T2P_OK; }
+  if (key == 33) { g_ffpo_merged = value != 0; return T2P_OK; }
+  if (key == 30) { set_gemm_split_consts(value, 0); return T2P_OK; }
+  if (key == 31) { set_gemm_split_consts(0, value); return T2P_OK; }
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) {
 #ifndef T2P_ABLATION

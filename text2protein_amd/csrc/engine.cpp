@@ -12,6 +12,7 @@
 #include <map>
 #include <mutex>
 #include <set>
+#include <thread>
 
 namespace t2p {
 
@@ -22,6 +23,8 @@ bool g_gn_small = true;
 bool g_lowp_residual = true;
 bool g_raw_copies = true;
 bool g_flash_attention = true;
+bool g_attn_merged = true;    // AttnBlockpp: NIN_2 . NIN_3 as one projection, output epilogue in the attention kernel (plan switch 32)
+bool g_ffpo_merged = true;    // SpatialTransformer: ff.net.2 and proj_out as one GEMM over [g | t] (plan switch 33)
 bool g_qkv_fused = true;      // self-attention: one q | k | v projection, V read row-major by the fused kernel (plan switch 25)
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
@@ -369,6 +372,26 @@ static std::vector<float> to_nk(const HostTensor& t, bool conv3x3, bool nin, int
   return t.data;
 }
 
+// out[M][N] = A[M][K] B[K][N] (row-major fp32; weight products formed once at load time), rows spread over a few threads
+static std::vector<float> host_matmul(const float* A, const float* B, int64_t M, int64_t K, int64_t N) {
+  std::vector<float> out((size_t)M * N, 0.f);
+  const int nt = (int)std::min<int64_t>(8, std::max<int64_t>(1, M / 16));
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      for (int64_t m = M * t / nt; m < M * (t + 1) / nt; ++m) {
+        float* o = out.data() + m * N;
+        for (int64_t k = 0; k < K; ++k) {
+          const float a = A[m * K + k];
+          const float* b = B + k * N;
+          for (int64_t n = 0; n < N; ++n) o[n] += a * b[n];
+        }
+      }
+    });
+  for (auto& x : th) x.join();
+  return out;
+}
+
 int Engine::upload_linear(const std::string& wname, const std::string& bname, int N, int K, DevLinear* out,
                           bool conv3x3, bool nin, int force_dtype) {
   std::vector<int64_t> shape;
@@ -523,6 +546,21 @@ int Engine::finalize() {
       T2P_TRY(upload_stack2(p + ".NIN_0.W", p + ".NIN_0.b", p + ".NIN_1.W", p + ".NIN_1.b", ci, ci, true, true, &l.qk));
       T2P_TRY(upload_linear(p + ".NIN_2.W", p + ".NIN_2.b", ci, ci, &l.v, false, true));
       T2P_TRY(upload_linear(p + ".NIN_3.W", p + ".NIN_3.b", ci, ci, &l.out, false, true));
+      if (cfg_.compute_dtype != DT_F32) {
+        const HostTensor* w2 = host(p + ".NIN_2.W", {ci, ci});      // NIN: [in][out]
+        const HostTensor* w3 = host(p + ".NIN_3.W", {ci, ci});
+        const HostTensor* b2 = host(p + ".NIN_2.b", {ci});
+        const HostTensor* b3 = host(p + ".NIN_3.b", {ci});
+        if (!w2 || !w3 || !b2 || !b3) return T2P_ERR_STATE;
+        HostTensor m;
+        m.shape = {ci, ci};
+        m.data = host_matmul(w2->data.data(), w3->data.data(), ci, ci, ci);       // [in][out]
+        std::vector<float> bb = host_matmul(b2->data.data(), w3->data.data(), 1, ci, ci);
+        for (int i = 0; i < ci; ++i) bb[i] += b3->data[i];
+        T2P_TRY(upload_matrix(pool_, to_nk(m, false, true), cfg_.compute_dtype, &l.v3.w));
+        T2P_TRY(upload_f32(bb, &l.v3.b));
+        l.v3.N = ci; l.v3.K = ci;
+      }
     } else {
       const std::string t = p + ".transformer_blocks.0";
       const int ctx = cfg_.context_dim;
@@ -566,6 +604,25 @@ int Engine::finalize() {
         l.ff1.K = ci;
       }
       T2P_TRY(upload_linear(t + ".ff.net.2.weight", t + ".ff.net.2.bias", ci, 4 * ci, &l.ff2));
+      if (cfg_.compute_dtype != DT_F32 && ci % 64 == 0) {
+        const HostTensor* wpo = host(p + ".proj_out.weight", {ci, ci, 1, 1});
+        const HostTensor* bpo = host(p + ".proj_out.bias", {ci});
+        const HostTensor* wf = host(t + ".ff.net.2.weight", {ci, 4 * ci});
+        const HostTensor* bf = host(t + ".ff.net.2.bias", {ci});
+        if (!wpo || !bpo || !wf || !bf) return T2P_ERR_STATE;
+        const std::vector<float> prod = host_matmul(wpo->data.data(), wf->data.data(), ci, ci, 4 * ci);    // [C][4 C]
+        std::vector<float> m((size_t)ci * 5 * ci), bb(ci);
+        for (int n = 0; n < ci; ++n) {
+          std::copy(prod.begin() + (size_t)n * 4 * ci, prod.begin() + (size_t)(n + 1) * 4 * ci, m.begin() + (size_t)n * 5 * ci);
+          std::copy(wpo->data.begin() + (size_t)n * ci, wpo->data.begin() + (size_t)(n + 1) * ci, m.begin() + (size_t)n * 5 * ci + 4 * ci);
+          double acc = bpo->data[n];
+          for (int j = 0; j < ci; ++j) acc += (double)wpo->data[(size_t)n * ci + j] * bf->data[j];
+          bb[n] = (float)acc;
+        }
+        T2P_TRY(upload_matrix(pool_, m, cfg_.compute_dtype, &l.ffpo.w));
+        T2P_TRY(upload_f32(bb, &l.ffpo.b));
+        l.ffpo.N = ci; l.ffpo.K = 5 * ci;
+      }
       T2P_TRY(upload_norm(t + ".norm1", ci, 1, &l.ln1));
       T2P_TRY(upload_norm(t + ".norm2", ci, 1, &l.ln2));
       T2P_TRY(upload_norm(t + ".norm3", ci, 1, &l.ln3));
@@ -931,16 +988,40 @@ int Engine::attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   POOL_GET(qk, char*, (size_t)rows * 2 * C * es);
   T2P_TRY(linear(a, false, L.qk, rows, qk, false, nullptr, 1.f, s));
   POOL_GET(vt, void*, (size_t)B * C * npad * es);
+  const bool olp = res_lowp();
+  const float att_scale = 1.f / std::sqrt((float)C);
+  const float out_alpha = cfg_.skip_rescale ? 0.70710678118654752440f : 1.f;
+  if (g_attn_merged && L.v3.w && attention_strip_eligible(dt, 1, n, n, C, 2 * C, 2 * C, npad, C) && (!x.lowp || olp)) {
+    // NIN_2 and NIN_3 as one projection (Layer::v3): the attention kernel's epilogue adds b2 W3 + b3 and the block input and
+    // scales by 1 / sqrt 2 -- (x + NIN_3(softmax(q k^T) v)) / sqrt 2, layers.py:170-176 -- no output-projection GEMM
+    DevLinear nob = L.v3;
+    nob.b = nullptr;
+    T2P_TRY(project_vt(dt, nob, a, C, B, n, npad, vt, s));
+    pool_.put(a);
+    POOL_GET(y, float*, (size_t)rows * C * (olp ? es : 4));
+    float* y_stats = nullptr;
+    if (g_fuse_gn_stats && n % 64 == 0) {
+      y_stats = (float*)pool_.get((size_t)(rows / 64) * C * 2 * 4);
+      if (!y_stats) return T2P_ERR_HIP;
+    }
+    StripEpilogue ep;
+    ep.bias = L.v3.b; ep.residual = x.p; ep.r_lowp = x.lowp ? 1 : 0; ep.ldr = C; ep.alpha = out_alpha; ep.out_f32 = olp ? 0 : 1;
+    ep.col_stats = y_stats;
+    T2P_TRY(launch_attention_strip(dt, qk, 2 * C, qk + (size_t)C * es, 2 * C, vt, npad, y, C, B, n, C, att_scale, s, &ep));
+    pool_.put(qk);
+    pool_.put(vt);
+    *out = Act{y, C, x.H, x.W, y_stats, olp};
+    return T2P_OK;
+  }
   T2P_TRY(project_vt(dt, L.v, a, C, B, n, npad, vt, s));
   pool_.put(a);
   POOL_GET(o, void*, (size_t)rows * C * es);
-  T2P_TRY(attention(qk, 2 * C, qk + (size_t)C * es, 2 * C, vt, npad, o, B, 1, n, n, C, 1.f / std::sqrt((float)C), s));
+  T2P_TRY(attention(qk, 2 * C, qk + (size_t)C * es, 2 * C, vt, npad, o, B, 1, n, n, C, att_scale, s));
   pool_.put(qk);
   pool_.put(vt);
-  const bool olp = res_lowp();
   POOL_GET(y, float*, (size_t)rows * C * (olp ? es : 4));
   float* y_stats = nullptr;
-  T2P_TRY(linear(o, false, L.out, rows, y, !olp, x.p, cfg_.skip_rescale ? 0.70710678118654752440f : 1.f, s, true, &y_stats, x.lowp));
+  T2P_TRY(linear(o, false, L.out, rows, y, !olp, x.p, out_alpha, s, true, &y_stats, x.lowp));
   pool_.put(o);
   *out = Act{y, C, x.H, x.W, y_stats, olp};
   return T2P_OK;
@@ -1005,6 +1086,24 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
       T2P_TRY(linear(ln, false, L.ff1, rows, u, true, nullptr, 1.f, s));
       T2P_TRY(launch_geglu(u, g, dt, rows, 4 * C, s, 1));
       pool_.put(u);
+    }
+    if (g_ffpo_merged && tl && L.ffpo.w) {
+      // ff.net.2 and proj_out as ONE product over [g | t] (Layer::ffpo): x + proj_out(t + ff2(g)), attention.py:213-215, 259-263
+      pool_.put(o);
+      const bool olp2 = res_lowp();
+      POOL_GET(y2, float*, (size_t)rows * C * (olp2 ? es : 4));
+      float* y2_stats = nullptr;
+      GemmParams q;
+      q.dtype = dt; q.a_f32 = 0; q.A0 = g; q.C0 = 4 * C; q.lda0 = 4 * C; q.A1 = t; q.C1 = C; q.lda1 = C;
+      q.Bw = L.ffpo.w; q.ldb = L.ffpo.K; q.M = (int)rows; q.N = C; q.bias_n = L.ffpo.b;
+      q.R = x.p; q.ldr = C; q.r_lowp = x.lowp ? 1 : 0;
+      q.C = y2; q.c_f32 = olp2 ? 0 : 1; q.ldc = C; q.rows_per_batch = n;
+      T2P_TRY(gemm_stats(q, &y2_stats, s));
+      pool_.put(g);
+      pool_.put(ln);
+      pool_.put(t);
+      *out = Act{y2, C, x.H, x.W, y2_stats, olp2};
+      return T2P_OK;
     }
     T2P_TRY(linear(g, false, L.ff2, rows, t, !tl, t, 1.f, s, true, nullptr, tl));
     pool_.put(g);

@@ -63,9 +63,15 @@ struct Layer {
   int temb_off = 0;
   // attn (AttnBlockpp): NIN_0|NIN_1 stacked, NIN_2, NIN_3
   DevLinear qk, v, out;
+  // 16-bit modes: NIN_2 and NIN_3 as one matrix -- rows of softmax(..) sum to 1, so NIN_3(P (h W2 + b2)) = P (h W2 W3) + (b2 W3 + b3):
+  // v3 = (W2 W3)^T [C][C] feeds the transposed value projection, v3.b = b2 W3 + b3 is added by the attention kernel's epilogue
+  DevLinear v3;
   // st (SpatialTransformer)
   DevLinear a1_qkv;   // 16-bit modes: to_q | to_k | to_v stacked, one projection GEMM for the self-attention
   DevLinear proj_in, proj_out, a1_qk, a1_v, a1_out, a2_q, a2_k, a2_v, a2_out, ff1, ff2;
+  // 16-bit modes: the feed-forward's second Linear and proj_out as one GEMM over [g | t] (no nonlinearity between them):
+  // proj_out(t + ff2(g)) = [W_po W_ff2 | W_po] [g ; t] + (W_po b_ff2 + b_po); ffpo.w = [C][4 C + C]
+  DevLinear ffpo;
   DevNorm ln1, ln2, ln3;
   void* ctx_k = nullptr;   // [B][T][C]      compute dtype (set_context)
   void* ctx_vt = nullptr;  // [B][C][Tpad]   compute dtype

@@ -2083,6 +2083,9 @@ static bool g_midsplit = false;  // mid-size problems: 256x256 tiles + split-K i
                                  // 4-stage 128x128 ring the unsplit plan is as fast and saves the second pass: -0.27 ms at cfg2)
 void set_gemm_midsplit(bool on) { g_midsplit = on; }
 
+static int g_split_tiles = 192, g_split_target = 256;     // plan constants (development keys 30 / 31)
+void set_gemm_split_consts(int tiles, int target) { if (tiles > 0) g_split_tiles = tiles; if (target > 0) g_split_target = target; }
+
 DmaPlan dma_plan(const GemmParams& p) {
   const long z = (long)p.nz0 * p.nz1;
   const int nk = ((p.C0 + p.C1 + 63) / 64) * p.taps + (p.CX0 + p.CX1) / 64;
@@ -2119,11 +2122,11 @@ DmaPlan dma_plan(const GemmParams& p) {
   int nsplit = 1;
   if (g_force_nsplit > 0) {
     if (can_split && g_force_nsplit > 1 && nk >= 2 * g_force_nsplit) nsplit = g_force_nsplit;
-  } else if (g_splitk && can_split && tiles < 192 && nk >= 16) {
+  } else if (g_splitk && can_split && tiles < g_split_tiles && nk >= 16) {
     // the tile grid cannot fill the chip and the K loop is long (low-resolution levels)
     // (tiles x splits ~ one workgroup per CU: a target of 256 measured 0.2 ms per step better than 384 at cfg2 and cfg3,
     // 128 .. 192 and 320 .. 768 worse; at least 4 K-tiles per split, 2 .. 12 within noise)
-    nsplit = std::min(std::min(nk / 4, (256 + tiles - 1) / tiles), 32);
+    nsplit = std::min(std::min(nk / 4, (g_split_target + tiles - 1) / tiles), 32);
   }
   while (nsplit > 1 && !fits(nsplit)) --nsplit;
   // 128 x 128 tiles on at most one workgroup per CU: such a launch is bound by the latency of its K-steps (0.47 us each with

@@ -158,6 +158,7 @@ bool gemm_fuses_geglu(const GemmParams& p);
 bool gemm_fuses_col_stats_lowp(const GemmParams& p);
 bool gemm_fuses_post_gn(const GemmParams& p, int groups);   // p without gn_*: would launch_gemm apply a following GroupNorm of `groups` groups?
 void set_gemm_post_gn(bool on);
+void set_gemm_split_consts(int tiles, int target);
 void set_gemm_dma(bool on);
 void set_gemm_debug(int v);
 void set_gemm_geom(int v);
@@ -171,6 +172,7 @@ void set_gemm_up4(bool on);
 void set_gemm_deep_ring(bool on);
 void set_gemm_fuse_shortcut(bool on);
 extern bool g_qkv_fused;
+extern bool g_attn_merged, g_ffpo_merged;
 extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible
 extern bool g_lowp_h1;         // engine: block-internal conv0 output stored in the compute dtype
 extern bool g_lowp_residual;   // engine: residual stream between blocks in the compute dtype (f16 mode)

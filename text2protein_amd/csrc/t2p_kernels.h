@@ -119,8 +119,19 @@ int launch_attention_flash(int dtype, const void* q, long ldq, const void* k, lo
 // ---- single-head attention with a wide head (AttnBlockpp, layers.py:160-176): d = 256 / 512 / 1024, n <= 1024, one launch --------
 extern bool g_attn_strip;
 bool attention_strip_eligible(int dtype, int heads, int nq, int nk, int d, long ldq, long ldk, long ldvt, long ldo);
+// optional epilogue: out = alpha (attention + bias[channel] + residual[query][channel]), stored fp32 or in the compute dtype, with
+// the per-64-query column sums / sums of squares of the stored fp32 values (col_stats [B n / 64][d][2], n % 64 == 0)
+struct StripEpilogue {
+  const float* bias = nullptr;
+  const void* residual = nullptr;
+  int r_lowp = 0;
+  long ldr = 0;
+  float alpha = 1.f;
+  int out_f32 = 0;
+  float* col_stats = nullptr;
+};
 int launch_attention_strip(int dtype, const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
-                           int B, int n, int d, float scale, hipStream_t s);
+                           int B, int n, int d, float scale, hipStream_t s, const StripEpilogue* ep = nullptr);
 
 int launch_convert(const float* in, void* out, int dtype, long n, hipStream_t s);
 int launch_widen(const void* in, int dtype, float* out, long n, hipStream_t s);   // compute dtype -> fp32
