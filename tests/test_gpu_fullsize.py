@@ -114,13 +114,17 @@ def test_cfg5_sampler_at_full_size():
     assert torch.equal(out[~free], coords[~free])               # known residues, the outside of the length mask, the mask channel
     assert float(out[free].abs().max()) > 1.0 and float((out[free] - coords[free]).abs().mean()) > 1.0
     assert int(free[0].sum()) == 7 * (100 * 100 - 89 * 89)      # 7 data channels x pairs inside the length mask with a selected residue
-    fn_c = sampling.get_sampling_fn(cfg, sde, (B, C, L, L), 1e-5, seed=5, force_classes=True)
-    out_c, _ = fn_c(m, condition=cond, context=ctx, n_iter=3, call_index=0)
-    torch.cuda.synchronize()
-    assert torch.equal(out_c[~free], coords[~free])
-    e = rel_l2(out_c[free], out[free])
-    print(f"cfg5 shape, 3 PC steps at 16 chains: class route vs fused route rel-L2 = {e:.3e}")
-    assert e < 1e-3
+    # the predictor / corrector classes on the operator ABI against the fused stepper, on identical injected noise
+    from helpers import CounterNoise
+    outs = {}
+    for force in (False, True):
+        fn_n = sampling.get_sampling_fn(cfg, sde, (B, C, L, L), 1e-5, seed=5, force_classes=force)
+        outs[force], _ = fn_n(m, condition=cond, context=ctx, n_iter=2, noise_fn=CounterNoise(77).draw)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[force][~free], coords[~free])
+    e = rel_l2(outs[True][free], outs[False][free])
+    print(f"cfg5 shape, 2 PC steps at 16 chains on injected noise: class route vs fused route rel-L2 = {e:.3e}")
+    assert e < 1e-5
 
 
 def test_midsize_splitk_plan_matches_unsplit(full):

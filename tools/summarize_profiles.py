@@ -31,12 +31,22 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--steps-in-trace", type=int, required=True, help="PC steps executed under the profiler (warmup + timed + roofline leg)")
+    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles"), help="output directory")
     a = ap.parse_args()
-    out = os.path.join(ROOT, "profiles")
+    out = a.out
     os.makedirs(out, exist_ok=True)
     ks = newest(os.path.join(a.stats, "*", "*kernel_stats.csv"))
-    shutil.copy(ks, os.path.join(out, f"{a.tag}_kernel_stats.csv"))
+    sfx = "" if a.workload == "cfg2" else "_" + a.workload
+    shutil.copy(ks, os.path.join(out, f"{a.tag}_kernel_stats{sfx}.csv"))
     rows = list(csv.DictReader(open(newest(os.path.join(a.stats, "*", "*kernel_trace.csv")))))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    # steady state = from the first dispatch of the first score evaluation (timestep_embedding_kernel); everything before it is set-up:
+    # weight uploads (one staged host-to-device copy = one __amd_rocclr_copyBuffer dispatch per tensor), text K/V projection, prior
+    first = next((i for i, r in enumerate(rows) if "timestep_embedding_kernel" in r["Kernel_Name"]), 0)
+    setup, rows = rows[:first], rows[first:]
+    copies_setup = sum("copyBuffer" in r["Kernel_Name"] or "fillBuffer" in r["Kernel_Name"] for r in setup)
+    copies_steady = sum("copyBuffer" in r["Kernel_Name"] or "fillBuffer" in r["Kernel_Name"] for r in rows)
     per = collections.defaultdict(lambda: [0, 0.0])
     tot = 0.0
     for r in rows:
@@ -46,10 +56,13 @@ def main():
         per[key][0] += 1
         per[key][1] += d
     n = a.steps_in_trace
-    with open(os.path.join(out, f"{a.tag}_kernels_by_shape.md"), "w") as f:
-        f.write(f"# {a.tag}: kernels by launch shape (rocprofv3 --kernel-trace, {n} PC steps, cfg2 f16)\n\n")
+    with open(os.path.join(out, f"{a.tag}_kernels_by_shape{sfx}.md"), "w") as f:
+        f.write(f"# {a.tag}: kernels by launch shape (rocprofv3 --kernel-trace, {n} PC steps, {a.workload} f16)\n\n")
+        f.write(f"Dispatches before the first score evaluation (set-up, not counted below): {len(setup)}, of which runtime copy / fill kernels "
+                f"(`__amd_rocclr_copyBuffer` / `fillBuffer`: the staged uploads of the weights): {copies_setup}.  Runtime copy / fill kernels "
+                f"inside the {n} PC steps: {copies_steady}.  Dispatches per PC step: {len(rows) / n:.1f}.\n\n")
         f.write(f"GPU time per PC step: {tot / n / 1e3:.2f} ms\n\n| kernel | grid (workgroups) | launches/step | ms/step | avg us |\n|---|---|---|---|---|\n")
-        for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])[:45]:
+        for k, v in sorted(per.items(), key=lambda kv: -kv[1][1])[:60]:
             f.write(f"| `{k[0]}` | {k[1]}x{k[2]}x{k[3]} | {v[0] / n:.1f} | {v[1] / n / 1e3:.2f} | {v[1] / v[0]:.1f} |\n")
     traffic = {}
     for kind, d in (("fetch", a.fetch), ("write", a.write)):
