@@ -280,6 +280,7 @@ def main():
         "traffic_measured_in_run": False,
     }
     if rank == 0 and not args.graph:
+        job.stepper.reset(0)
         out["dispatches_per_step"] = job.stepper.count_dispatches(job.x, job.x_mean)     # graph nodes of one captured PC step
 
     if rank == 0 and not args.no_roofline:
@@ -325,7 +326,7 @@ def main():
         out["f32"] = {"value": v32, "unit": "samples/s", "ms_per_step": d32 * 1e3, "steps": args.f32_steps, "warmup": 1, "dtype": "f32",
                       "mfma_frac_end_to_end": v32 * 2 * N * alg / (MFMA_PEAK_TFLOPS["f32"] * 1e12), "peak": MFMA_PEAK_TFLOPS["f32"],
                       "finite": bool(torch.isfinite(job.x_mean).all().item()),
-                      "dispatches_per_step": st32.count_dispatches(job.x, job.x_mean)}
+                      "dispatches_per_step": (st32.reset(0), st32.count_dispatches(job.x, job.x_mean))[1]}
         if not args.no_roofline:
             out["f32"]["roofline"] = kernel_roofline(job, st32, lib, MFMA_PEAK_TFLOPS["f32"])
         del st32, m32

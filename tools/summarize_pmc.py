@@ -25,6 +25,7 @@ def short(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", required=True)
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles"), help="output directory")
     ap.add_argument("dirs", nargs="+")
     a = ap.parse_args()
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
@@ -46,7 +47,8 @@ def main():
         if "TCC_HIT_sum" in o and "TCC_MISS_sum" in o:
             o["l2_hit_rate"] = o["TCC_HIT_sum"] / max(o["TCC_HIT_sum"] + o["TCC_MISS_sum"], 1.0)
         out[nm] = o
-    path = os.path.join(ROOT, "profiles", f"{a.tag}_pmc_sq_tcc.json")
+    os.makedirs(a.out, exist_ok=True)
+    path = os.path.join(a.out, f"{a.tag}_pmc_sq_tcc.json")
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
     print("wrote", path, len(out), "kernels")
 
