@@ -112,6 +112,13 @@ void t2p_sampler_destroy(t2p_sampler* s);
 /* Seed of the on-device Philox noise of the following steps.  The reference draws fresh torch.randn noise on
  * every call of pc_sampler; the Python mirror derives one seed per (seed, call index) and sets it here. */
 int t2p_sampler_set_seed(t2p_sampler* s, uint64_t seed);
+/* VP SDE (VPSDE, sde_lib.py:106-157; score function models/utils.py:138-157; Langevin alpha sampling.py:184-186) in the fused
+ * loop.  A sampler created with cfg.sde = T2P_SDE_VP takes g_table[i] = sqrt(beta_k) and label_table[i] = floor(t_i (N - 1)) at
+ * t2p_sampler_create and, here, four more host tables of N floats for loop step i (t_i = linspace(T, eps, N)[i], k = the
+ * reference's truncated timestep): label_f = t_i (N - 1) (the fractional label the network embeds), score_scale = -1 /
+ * sqrt_1m_alphas_cumprod[label] (score = -model / std), x_coef = 2 - sqrt(alpha_k) (x - f with f = (sqrt(alpha) - 1) x),
+ * corr_alpha = alpha_k. */
+int t2p_sampler_set_vp_tables(t2p_sampler* s, const float* label_f, const float* score_scale, const float* x_coef, const float* corr_alpha);
 /* Global-batch Langevin step size (the reference's DataParallel run takes the norm means over the whole batch,
  * sampling.py:193-195; cfg.global_batch > cfg.batch): every corrector step writes {sum_b ||grad_b||,
  * sum_b ||noise_b||} of this process's chains to `device_sums2` (caller-owned device float[2]) and calls

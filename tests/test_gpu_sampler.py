@@ -247,8 +247,8 @@ def test_two_corrector_steps_match_oracle():
 
 
 def test_vp_sde_route_matches_reference_run():
-    """VP SDE through the predictor / corrector classes (fractional time labels in the engine) against the
-    reference's own 40-step VP run."""
+    """VP SDE (fractional time labels in the engine, score = -model / std, alpha-scaled Langevin step, DDPM discretisation) through
+    the predictor / corrector classes AND through the fused sampler (t2p_sampler_set_vp_tables) against the reference's own 40-step VP run."""
     from text2protein_amd import synth, sde_lib, sampling
     from text2protein_amd.config import tiny_config
     from text2protein_amd.model import HipScoreModel
@@ -258,14 +258,20 @@ def test_vp_sde_route_matches_reference_run():
     model = HipScoreModel(cfg, dtype="f32")
     model.load_state_dict(synth.synth_state_dict(cfg, int(g["seed"])))
     sde = sde_lib.VPSDE(beta_min=cfg.model.beta_min, beta_max=cfg.model.beta_max, N=cfg.model.num_scales)
-    fn = sampling.get_sampling_fn(cfg, sde, (2, 5, 16, 16), 1e-3)
-    it = iter([torch.from_numpy(z) for z in g["noise"]])
-    out, nfe = fn(model, condition={}, context=torch.from_numpy(g["context"]), noise_fn=lambda shp: next(it))
-    torch.cuda.synchronize()
-    assert nfe == int(g["nfe"])
-    err = rel_l2(out.cpu(), g["sample"])
-    print(f"VP route: final sample rel-L2 vs reference = {err:.3e}")
-    assert err < 1e-4
+    for force in (True, False):          # the predictor / corrector classes, then the fused C++ loop (per-step VP tables on the device)
+        fn = sampling.get_sampling_fn(cfg, sde, (2, 5, 16, 16), 1e-3, force_classes=force)
+        it = iter([torch.from_numpy(z) for z in g["noise"]])
+        out, nfe = fn(model, condition={}, context=torch.from_numpy(g["context"]), noise_fn=lambda shp: next(it))
+        torch.cuda.synchronize()
+        assert nfe == int(g["nfe"])
+        err = rel_l2(out.cpu(), g["sample"])
+        print(f"VP route ({'classes' if force else 'fused sampler'}): final sample rel-L2 vs reference = {err:.3e}")
+        assert err < 1e-4
+    # the fused VP loop on device noise: finite, reproducible, and the class route refuses nothing it used to accept
+    fn = sampling.get_sampling_fn(cfg, sde, (2, 5, 16, 16), 1e-3, seed=3)
+    a, _ = fn(model, condition={}, context=torch.from_numpy(g["context"]), call_index=0)
+    b, _ = fn(model, condition={}, context=torch.from_numpy(g["context"]), call_index=0)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
 def test_graph_replay_is_bit_identical_to_eager_steps():

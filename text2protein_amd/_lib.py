@@ -61,6 +61,7 @@ SIGNATURES = {
     "t2p_sampler_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "t2p_sampler_step_graph": (_i, [_vp, _vp, _vp, _vp]),
     "t2p_sampler_run": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "t2p_sampler_set_vp_tables": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "t2p_sampler_count_dispatches": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int)]),
     "t2p_op_gemm": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _vp, _f, _vp]),
     "t2p_op_conv3x3_shortcut": (_i, [_i, _vp, _vp, _vp, _vp, _i, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -142,6 +142,13 @@ int t2p_sampler_set_norm_allreduce(t2p_sampler* s, float* device_sums2, t2p_allr
   API_END
 }
 
+int t2p_sampler_set_vp_tables(t2p_sampler* s, const float* label_f, const float* score_scale, const float* x_coef, const float* corr_alpha) {
+  API_BEGIN
+  T2P_REQUIRE(s, "null sampler");
+  return s->impl.set_vp_tables(label_f, score_scale, x_coef, corr_alpha);
+  API_END
+}
+
 int t2p_sampler_reset(t2p_sampler* s, int step, void* stream) {
   API_BEGIN
   T2P_REQUIRE(s, "null sampler");

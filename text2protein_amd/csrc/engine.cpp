@@ -1201,7 +1201,7 @@ int Engine::set_context(const float* ctx, int B, int T, hipStream_t s) {
 
 // UNetModel.forward (ncsnpp.py:220-263)
 int Engine::score(const float* x, const int* labels, const int* step_counter, float* out, int B, hipStream_t s,
-                  const float* labels_f, const int* label_table) {
+                  const float* labels_f, const int* label_table, const float* label_f_table) {
   T2P_REQUIRE(finalized_, "finalize the engine first");
   T2P_REQUIRE(x && out && B > 0 && (labels || step_counter), "score arguments");
   const int L = cfg_.max_res_num, HW = L * L, Cx = cfg_.num_channels, N = cfg_.num_scales;
@@ -1214,7 +1214,8 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
   POOL_GET(tb, float*, (size_t)R * temb_total_ * 4);
   T2P_REQUIRE(!labels_f || labels, "fractional labels come with integer labels (sigma index)");
   T2P_REQUIRE(!label_table || (!labels && step_counter), "a label table goes with the device step counter");
-  T2P_TRY(launch_timestep_embedding(labels, labels_f, step_counter, emb, R, nf_, s, label_table, N));
+  T2P_REQUIRE(!label_f_table || label_table, "the fractional label table goes with the integer one (sigma index)");
+  T2P_TRY(launch_timestep_embedding(labels, labels_f, step_counter, emb, R, nf_, s, label_table, N, label_f_table));
   T2P_TRY(launch_small_linear(emb, (const float*)pre0_.w, pre0_.b, t1, R, nf_, temb_dim_, 0, s));
   T2P_TRY(launch_small_linear(t1, (const float*)pre1_.w, pre1_.b, t2, R, temb_dim_, temb_dim_, 0, s));
   T2P_TRY(launch_small_linear(t2, (const float*)dense_all_.w, dense_all_.b, tb, R, temb_dim_, temb_total_, 1, s));
@@ -1311,7 +1312,8 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
 Sampler::Sampler(Engine* e, const t2p_sampler_config& cfg) : e_(e), cfg_(cfg) {}
 
 int Sampler::init(const float* g_table_host, const int32_t* label_table_host) {
-  T2P_REQUIRE(cfg_.sde == T2P_SDE_VE, "the fused sampler covers the VE SDE (every shipped config); VP runs through the operator API");
+  T2P_REQUIRE(cfg_.sde == T2P_SDE_VE || cfg_.sde == T2P_SDE_VP, "the fused sampler covers the VE and VP SDEs");
+  T2P_REQUIRE(cfg_.sde == T2P_SDE_VE || (g_table_host && label_table_host), "the VP SDE needs its G and label tables (t2p_sampler_create) and t2p_sampler_set_vp_tables");
   T2P_REQUIRE(cfg_.N == e_->cfg().num_scales, "sde.N must equal model.num_scales");
   T2P_REQUIRE(cfg_.batch > 0 && cfg_.global_batch >= cfg_.batch && cfg_.n_steps_each >= 1, "sampler config");
   T2P_REQUIRE(cfg_.eps >= 0.0 && cfg_.eps < 1.0, "eps must lie in [0, T)");
@@ -1368,6 +1370,21 @@ int Sampler::reset(int step, hipStream_t s) {
   return T2P_OK;
 }
 
+int Sampler::set_vp_tables(const float* label_f, const float* score_scale, const float* x_coef, const float* corr_alpha) {
+  T2P_REQUIRE(cfg_.sde == T2P_SDE_VP, "VP tables belong to a sampler created with sde = T2P_SDE_VP");
+  T2P_REQUIRE(label_f && score_scale && x_coef && corr_alpha, "null table");
+  DevPool& pool = e_->pool();
+  const size_t bytes = (size_t)cfg_.N * 4;
+  float** dst[4] = {&vp_label_f_, &vp_score_scale_, &vp_x_coef_, &vp_alpha_};
+  const float* src[4] = {label_f, score_scale, x_coef, corr_alpha};
+  for (int i = 0; i < 4; ++i) {
+    if (!*dst[i]) *dst[i] = (float*)pool.persistent(bytes);
+    if (!*dst[i]) return T2P_ERR_HIP;
+    T2P_HIP_CHECK(hipMemcpy(*dst[i], src[i], bytes, hipMemcpyHostToDevice));
+  }
+  return T2P_OK;
+}
+
 int Sampler::set_norm_allreduce(float* sums, t2p_allreduce_fn fn, void* user) {
   T2P_REQUIRE((sums == nullptr) == (fn == nullptr), "the sums buffer and the all-reduce callback go together");
   sums_ext_ = sums; allreduce_ = fn; allreduce_user_ = user;
@@ -1384,9 +1401,17 @@ int Sampler::step(float* x, float* x_mean, const float* nc, const float* np, hip
   // processes, i.e. the all-reduce hook; without it the mean runs over this process's chains
   T2P_REQUIRE(cfg_.global_batch == cfg_.batch || allreduce_, "global_batch > batch needs t2p_sampler_set_norm_allreduce");
   const int B = cfg_.batch;
+  const bool vp = cfg_.sde == T2P_SDE_VP;
+  T2P_REQUIRE(!vp || vp_label_f_, "VP SDE: call t2p_sampler_set_vp_tables first");
   float* sums = allreduce_ ? sums_ext_ : sums_;
+  // score function (models/utils.py:138-171): VE = the network output at the integer label; VP = -output / std at the fractional one
+  auto score_fn = [&]() -> int {
+    T2P_TRY(e_->score(x, nullptr, step_dev_, score_, B, s, nullptr, label_table_, vp ? vp_label_f_ : nullptr));
+    if (vp) T2P_TRY(launch_scale_by_table(score_, n_, vp_score_scale_, step_dev_, cfg_.N, s));
+    return T2P_OK;
+  };
   for (int k = 0; k < cfg_.n_steps_each; ++k) {
-    T2P_TRY(e_->score(x, nullptr, step_dev_, score_, B, s, nullptr, label_table_));
+    T2P_TRY(score_fn());
     const float* z = nc;
     if (!z) {
       T2P_TRY(launch_philox_normal(noise_, n_, cfg_.seed, 2ull * k + 2, step_dev_, s));
@@ -1399,9 +1424,10 @@ int Sampler::step(float* x, float* x_mean, const float* nc, const float* np, hip
     }
     SdeUpdateArgs a;
     a.x = x; a.score = score_; a.noise = z; a.mask = mask_; a.x_initial = x_init_; a.x_out = x; a.n = n_;
-    T2P_TRY(launch_langevin_update(a, sums, (float)(allreduce_ ? cfg_.global_batch : B), (float)cfg_.snr, 1.f, s));
+    T2P_TRY(launch_langevin_update(a, sums, (float)(allreduce_ ? cfg_.global_batch : B), (float)cfg_.snr, 1.f, s,
+                                   vp ? vp_alpha_ : nullptr, vp ? step_dev_ : nullptr, vp ? cfg_.N : 0));
   }
-  T2P_TRY(e_->score(x, nullptr, step_dev_, score_, B, s, nullptr, label_table_));
+  T2P_TRY(score_fn());
   const float* z = np;
   if (!z) {
     T2P_TRY(launch_philox_normal(noise_, n_, cfg_.seed, 1, step_dev_, s));
@@ -1410,7 +1436,7 @@ int Sampler::step(float* x, float* x_mean, const float* nc, const float* np, hip
   SdeUpdateArgs a;
   a.x = x; a.score = score_; a.noise = z; a.mask = mask_; a.x_initial = x_init_; a.x_out = x;
   a.x_mean_out = x_mean ? x_mean : xmean_; a.n = n_;
-  T2P_TRY(launch_predictor_update(a, g_table_, step_dev_, 0.f, cfg_.probability_flow, s, cfg_.N));
+  T2P_TRY(launch_predictor_update(a, g_table_, step_dev_, 0.f, cfg_.probability_flow, s, cfg_.N, vp ? vp_x_coef_ : nullptr));
   T2P_TRY(launch_add_int(step_dev_, 1, s));
   ++host_step_;
   return T2P_OK;
@@ -1485,7 +1511,7 @@ int Sampler::run(float* x, float* out, int prior_given, int n_steps, hipStream_t
   if (!prior_given) {
     // VESDE.prior_sampling (sde_lib.py:229-230) then where(mask, x, x_initial)
     T2P_TRY(launch_philox_normal(x, n_, cfg_.seed, 0, nullptr, s));
-    T2P_TRY(launch_scale(x, n_, (float)cfg_.sigma_max, s));
+    if (cfg_.sde == T2P_SDE_VE) T2P_TRY(launch_scale(x, n_, (float)cfg_.sigma_max, s));     // VP prior: N(0, 1) (sde_lib.py:133-134)
     if (mask_) T2P_TRY(launch_apply_mask(x, mask_, x_init_, n_, s));
   }
   for (int i = 0; i < n_steps; ++i) T2P_TRY(step(x, xmean_, nullptr, nullptr, s));

@@ -109,8 +109,9 @@ class Engine {
   int set_context(const float* ctx, int B, int T, hipStream_t s);
   // labels == nullptr: every row uses *step_counter (device int)
   // label_table (with step_counter): device int[num_scales], the time label of loop step i (fused sampler)
+  // label_f_table (with step_counter): device float[num_scales], the fractional time label of loop step i (VP SDE)
   int score(const float* x, const int* labels, const int* step_counter, float* out, int B, hipStream_t s,
-            const float* labels_f = nullptr, const int* label_table = nullptr);
+            const float* labels_f = nullptr, const int* label_table = nullptr, const float* label_f_table = nullptr);
   int64_t device_bytes() const { return (int64_t)pool_.held_bytes(); }
   const t2p_model_config& cfg() const { return cfg_; }
   DevPool& pool() { return pool_; }
@@ -177,6 +178,8 @@ class Sampler {
   // device float[2] the norm sums of this process's chains are written to; `fn` must sum it over all processes
   // in stream order before returning control (e.g. one RCCL all_reduce enqueued on `stream`)
   int set_norm_allreduce(float* sums, t2p_allreduce_fn fn, void* user);
+  // VP SDE (sde_lib.py:106-157) in the fused loop: per-step host tables of N floats (see t2p_sampler_set_vp_tables)
+  int set_vp_tables(const float* label_f, const float* score_scale, const float* x_coef, const float* corr_alpha);
   int reset(int step, hipStream_t s);
   int step(float* x, float* x_mean, const float* nc, const float* np, hipStream_t s);
   // step() through a captured hipGraph (device noise only): first call with a given (x, x_mean,
@@ -199,6 +202,10 @@ class Sampler {
   float* sums_ = nullptr;
   float* xmean_ = nullptr;
   int* label_table_ = nullptr;     // device int[N]: time label of loop step i
+  float* vp_label_f_ = nullptr;    // VP: device float[N] each
+  float* vp_score_scale_ = nullptr;
+  float* vp_x_coef_ = nullptr;
+  float* vp_alpha_ = nullptr;
   int host_step_ = 0;              // host mirror of *step_dev_ (bounds check: the tables have N entries)
   float* sums_ext_ = nullptr;
   t2p_allreduce_fn allreduce_ = nullptr;

@@ -1091,13 +1091,16 @@ int launch_nchw_to_nhwc(const float* x, float* out, int B, int C, int HW, int Cp
 
 // ================================== time embedding ========================================================
 __global__ void timestep_embedding_kernel(const int* labels, const float* labels_f, const int* step_counter,
-                                          const int* label_table, int n_table, float* emb, int rows, int dim) {
+                                          const int* label_table, int n_table, float* emb, int rows, int dim, const float* label_f_table) {
   const int half = dim / 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * dim) return;
   const int r = i / dim, k = i - r * dim;
   // fused sampler: the time label of loop step i is label_table[i] (get_score_fn, models/utils.py:159-171)
-  const float t = labels_f ? labels_f[r] : (float)(labels ? labels[r] : (label_table ? label_table[min(max(*step_counter, 0), n_table - 1)] : *step_counter));
+  // (VP SDE in the fused sampler: fractional labels t (N - 1) per loop step, models/utils.py:150-152)
+  const float t = labels_f ? labels_f[r]
+                : (label_f_table ? label_f_table[min(max(*step_counter, 0), n_table - 1)]
+                : (float)(labels ? labels[r] : (label_table ? label_table[min(max(*step_counter, 0), n_table - 1)] : *step_counter)));
   // reference: emb = log(10000) / (half - 1) as a python float, then exp(arange * -emb) in fp32
   const float e = (float)(9.210340371976184 / (double)(half - 1));
   float val = 0.f;
@@ -1111,12 +1114,12 @@ __global__ void timestep_embedding_kernel(const int* labels, const float* labels
 }
 
 int launch_timestep_embedding(const int* labels, const float* labels_f, const int* step_counter, float* emb, int rows, int dim,
-                              hipStream_t s, const int* label_table, int n_table) {
+                              hipStream_t s, const int* label_table, int n_table, const float* label_f_table) {
   T2P_REQUIRE((labels || labels_f || step_counter) && emb && dim >= 4, "timestep embedding arguments");
   T2P_REQUIRE(!label_table || (step_counter && n_table > 0), "label_table needs the step counter and its length");
   const int tot = rows * dim;
   hipLaunchKernelGGL(timestep_embedding_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, labels, labels_f, step_counter, label_table, n_table,
-                     emb, rows, dim);
+                     emb, rows, dim, label_f_table);
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }
@@ -1199,8 +1202,9 @@ int launch_langevin_norms(const float* grad, const float* noise, int B, long per
 }
 
 __global__ __launch_bounds__(256) void langevin_update_kernel(SdeUpdateArgs a, const float* sums, float batch_total, float snr,
-                                                              float alpha) {
-  // step_size = (snr * noise_norm / grad_norm)^2 * 2 * alpha   (sampling.py:195)
+                                                              float alpha, const float* alpha_table, const int* step_counter, int n_table) {
+  // step_size = (snr * noise_norm / grad_norm)^2 * 2 * alpha   (sampling.py:195); VP: alpha = sde.alphas[timestep] (sampling.py:184-186)
+  if (alpha_table) alpha = alpha_table[min(max(*step_counter, 0), n_table - 1)];
   const float gn = sums[0] / batch_total, nn = sums[1] / batch_total;
   const float r = snr * nn / gn;
   const float step = r * r * 2.f * alpha;
@@ -1216,24 +1220,27 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(SdeUpdateArgs a, c
 }
 
 int launch_langevin_update(const SdeUpdateArgs& a, const float* sums, float batch_total, float snr, float alpha,
-                           hipStream_t s) {
+                           hipStream_t s, const float* alpha_table, const int* step_counter, int n_table) {
+  T2P_REQUIRE(!alpha_table || (step_counter && n_table > 0), "alpha_table needs the step counter and its length");
   T2P_REQUIRE(a.x && a.score && a.noise && a.x_out && sums && a.n > 0, "langevin_update arguments");
   T2P_REQUIRE(!a.mask || a.x_initial, "mask needs x_initial");
-  hipLaunchKernelGGL(langevin_update_kernel, dim3(ew_grid(a.n)), dim3(256), 0, s, a, sums, batch_total, snr, alpha);
+  hipLaunchKernelGGL(langevin_update_kernel, dim3(ew_grid(a.n)), dim3(256), 0, s, a, sums, batch_total, snr, alpha, alpha_table, step_counter, n_table);
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }
 
 __global__ __launch_bounds__(256) void predictor_update_kernel(SdeUpdateArgs a, const float* G_table, const int* step_counter,
-                                                               float G_value, int probability_flow, int n_table) {
+                                                               float G_value, int probability_flow, int n_table, const float* x_coef_table) {
   // the host refuses steps >= N (Sampler::step); the clamp is a second guard against reading past the table
   const int si = G_table ? min(max(*step_counter, 0), n_table - 1) : 0;
   const float G = G_table ? G_table[si] : G_value;
   const float g2 = G * G * (probability_flow ? 0.5f : 1.f);
   const float gz = probability_flow ? 0.f : G;
+  // VP (sde_lib.py:148-157): f = (sqrt(alpha) - 1) x, so x - f = (2 - sqrt(alpha)) x: the coefficient comes from a per-step table
+  const float xc = x_coef_table ? x_coef_table[si] : 1.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) {
-    // rev_f = -G^2 * score ; x_mean = x - rev_f ; x = x_mean + G z   (sde_lib.py:96-101, sampling.py:162-167)
-    const float xm = a.x[i] + g2 * a.score[i];
+    // rev_f = f - G^2 * score ; x_mean = x - rev_f ; x = x_mean + G z   (sde_lib.py:96-101, sampling.py:162-167)
+    const float xm = xc * a.x[i] + g2 * a.score[i];
     float xn = xm + gz * a.noise[i];
     if (a.mask && !a.mask[i]) xn = a.x_initial[i];
     a.x_out[i] = xn;
@@ -1242,12 +1249,25 @@ __global__ __launch_bounds__(256) void predictor_update_kernel(SdeUpdateArgs a, 
 }
 
 int launch_predictor_update(const SdeUpdateArgs& a, const float* G_table, const int* step_counter, float G_value,
-                            int probability_flow, hipStream_t s, int n_table) {
+                            int probability_flow, hipStream_t s, int n_table, const float* x_coef_table) {
+  T2P_REQUIRE(!x_coef_table || G_table, "the x coefficient table goes with the G table");
   T2P_REQUIRE(a.x && a.score && a.noise && a.x_out && a.n > 0, "predictor_update arguments");
   T2P_REQUIRE(!a.mask || a.x_initial, "mask needs x_initial");
   T2P_REQUIRE(!G_table || (step_counter && n_table > 0), "G_table needs the step counter and its length");
   hipLaunchKernelGGL(predictor_update_kernel, dim3(ew_grid(a.n)), dim3(256), 0, s, a, G_table, step_counter, G_value,
-                     probability_flow, n_table);
+                     probability_flow, n_table, x_coef_table);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// x *= table[*step]   (VP score: -model / std of the step's time label, models/utils.py:153-157)
+__global__ __launch_bounds__(256) void scale_by_table_kernel(float* x, long n, const float* table, const int* step_counter, int n_table) {
+  const float a = table[min(max(*step_counter, 0), n_table - 1)];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= a;
+}
+int launch_scale_by_table(float* x, long n, const float* table, const int* step_counter, int n_table, hipStream_t s) {
+  T2P_REQUIRE(x && table && step_counter && n > 0 && n_table > 0, "scale_by_table arguments");
+  hipLaunchKernelGGL(scale_by_table_kernel, dim3(ew_grid(n)), dim3(256), 0, s, x, n, table, step_counter, n_table);
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }

@@ -77,8 +77,9 @@ int launch_nchw_to_nhwc(const float* x, float* out, int B, int C, int HW, int Cp
 // labels_f (optional): fractional time values for the embedding (VP path: labels = t * (N - 1),
 // reference models/utils.py:150-152); the sigma lookup always uses the integer labels
 // label_table (optional, with step_counter): the label is label_table[*step_counter] instead of *step_counter
+// label_f_table (optional, with step_counter): fractional label of loop step i (VP SDE in the fused sampler)
 int launch_timestep_embedding(const int* labels, const float* labels_f, const int* step_counter, float* emb, int rows,
-                              int dim, hipStream_t s, const int* label_table = nullptr, int n_table = 0);
+                              int dim, hipStream_t s, const int* label_table = nullptr, int n_table = 0, const float* label_f_table = nullptr);
 // out[r][n] = bias[n] + sum_k act(in[r][k]) * W[n][k]   (fp32; act = SiLU when silu != 0)
 int launch_small_linear(const float* in, const float* W, const float* bias, float* out, int rows, int K, int N,
                         int silu, hipStream_t s);
@@ -99,12 +100,15 @@ struct SdeUpdateArgs {
 };
 // corrector: step = (snr * mean_norm_noise / mean_norm_grad)^2 * 2 * alpha, with the two means
 // = sums[] / batch_total (batch_total may exceed the local batch: global-batch semantics)
+// alpha_table (optional): alpha = alpha_table[*step_counter] (VP: sde.alphas[timestep], sampling.py:184-186)
 int launch_langevin_update(const SdeUpdateArgs& a, const float* sums, float batch_total, float snr, float alpha,
-                           hipStream_t s);
+                           hipStream_t s, const float* alpha_table = nullptr, const int* step_counter = nullptr, int n_table = 0);
 // predictor: x_mean = x + G^2 * score * (0.5 if probability_flow); x = x_mean + (0 if pf else G) z
 // G = G_table[*step_counter] when G_table != null, else G_value
+// x_coef_table (optional, with G_table): x_mean = x_coef[step] x + ... (VP: 2 - sqrt(alpha), sde_lib.py:148-157)
 int launch_predictor_update(const SdeUpdateArgs& a, const float* G_table, const int* step_counter, float G_value,
-                            int probability_flow, hipStream_t s, int n_table = 0);
+                            int probability_flow, hipStream_t s, int n_table = 0, const float* x_coef_table = nullptr);
+int launch_scale_by_table(float* x, long n, const float* table, const int* step_counter, int n_table, hipStream_t s);
 // noise[i] = N(0,1) from Philox4x32-10 keyed by (seed, stream); counter = element index / 4
 int launch_philox_normal(float* out, long n, unsigned long long seed, unsigned long long stream,
                          const int* step_counter, hipStream_t s);

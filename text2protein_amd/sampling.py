@@ -248,16 +248,21 @@ class PCStepper:
         over several processes (the reference's DataParallel semantics, sampling.py:193-195): ``all_reduce`` is
         called once per corrector step with a 2-float device tensor it must sum over the processes in place,
         in stream order (``text2protein_amd.distributed.allreduce_norm_sums``)."""
-        if not isinstance(sde, sde_lib.VESDE):
-            raise T2PError("the fused stepper covers the VE SDE; other SDEs run through the predictor/corrector classes")
+        vp = isinstance(sde, sde_lib.VPSDE)
+        if not (vp or isinstance(sde, sde_lib.VESDE)):
+            raise T2PError("the fused stepper covers the VE and VP SDEs; others run through the predictor/corrector classes")
         if not isinstance(model, HipScoreModel):
             raise T2PError("the fused stepper needs a HipScoreModel")
         self.model, self.lib = model, model.lib
         sc = SamplerConfig()
-        sc.sde = _lib.SDE_VE
+        sc.sde = _lib.SDE_VP if vp else _lib.SDE_VE
         sc.N = sde.N
-        sc.sigma_min, sc.sigma_max = float(sde.sigma_min), float(sde.sigma_max)
-        sc.beta_min, sc.beta_max = 0.1, 20.0
+        if vp:
+            sc.sigma_min, sc.sigma_max = 0.01, 1.0
+            sc.beta_min, sc.beta_max = float(sde.beta_0), float(sde.beta_1)
+        else:
+            sc.sigma_min, sc.sigma_max = float(sde.sigma_min), float(sde.sigma_max)
+            sc.beta_min, sc.beta_max = 0.1, 20.0
         sc.snr = float(snr)
         sc.n_steps_each = int(n_steps)
         sc.probability_flow = int(bool(probability_flow))
@@ -270,10 +275,13 @@ class PCStepper:
         sc.seed = int(seed) & _M64
         g = sde.g_table(eps)                       # the reference's own float32 arithmetic
         labels = sde.label_table(eps)
+        vp_tables = sde.vp_tables(eps) if vp else None
         h = C.c_void_p()
         check(self.lib.t2p_sampler_create(model._h, C.byref(sc), C.c_void_p(g.data_ptr()), C.c_void_p(labels.data_ptr()),
                                           C.byref(h)))
         self._h = h
+        if vp:
+            check(self.lib.t2p_sampler_set_vp_tables(h, *[C.c_void_p(t.data_ptr()) for t in vp_tables]))
         self._keep = ()
         self.N = int(sde.N)
         if all_reduce is not None:
@@ -383,7 +391,7 @@ def get_pc_sampler(sde, shape, predictor, corrector, snr, n_steps=1, probability
     device = torch.device("cuda:0" if str(device) == "cuda" else device)
     if device.type != "cuda":
         raise T2PError("the HIP sampler needs a GPU device (no CPU fallback)")
-    fused_ok = (isinstance(sde, sde_lib.VESDE) and predictor is ReverseDiffusionPredictor
+    fused_ok = (isinstance(sde, (sde_lib.VESDE, sde_lib.VPSDE)) and predictor is ReverseDiffusionPredictor
                 and corrector is LangevinCorrector and not force_classes)
     state = {"sampler": None, "model": None, "calls": 0}
 

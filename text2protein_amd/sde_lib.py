@@ -108,6 +108,32 @@ class VPSDE(SDE):
         return torch.sqrt(alpha) - 1.0, torch.sqrt(beta)
 
 
+    # ---- per-step tables of the fused sampler (loop step i of ``timesteps = linspace(T, eps, N)``, sampling.py:257) ----
+    def _steps(self, eps):
+        ts = torch.linspace(self.T, eps, self.N)
+        return ts, (ts * (self.N - 1) / self.T).long()
+
+    def g_table(self, eps):
+        """G = sqrt(beta_k) of loop step i (sde_lib.py:148-157)."""
+        ts, _ = self._steps(eps)
+        return self.discretize_coeffs(ts)[1].float().contiguous()
+
+    def label_table(self, eps):
+        """Integer part of the time label of loop step i (index of the std / sigma tables, models/utils.py:150-153)."""
+        ts, _ = self._steps(eps)
+        return (ts * (self.N - 1)).long().to(torch.int32).contiguous()
+
+    def vp_tables(self, eps):
+        """(label_f, score_scale, x_coef, corr_alpha), float32[N] each: the fractional label ``t (N - 1)`` the network embeds,
+        ``-1 / sqrt_1m_alphas_cumprod[label]`` (models/utils.py:150-157), ``2 - sqrt(alpha_k)`` (x - f, sde_lib.py:148-157) and
+        ``alpha_k`` (sampling.py:184-186), all in the reference's float32 arithmetic."""
+        ts, k = self._steps(eps)
+        label_f = ts * (self.N - 1)
+        std = self.sqrt_1m_alphas_cumprod[label_f.long()]
+        a, _ = self.discretize_coeffs(ts)
+        return tuple(t.float().contiguous() for t in (label_f, -1.0 / std, 1.0 - a, self.alphas[k]))
+
+
 class subVPSDE(SDE):
     """Present for the config surface only: the reference's ``subVPSDE.sde`` does not accept the
     ``context`` argument its callers pass (sde_lib.py:177 vs :89), so it cannot be sampled there
