@@ -488,6 +488,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 27) { t2p::g_gn_apply_cols = value != 0; return T2P_OK; }
   if (key == 28) { set_gemm_post_gn(value != 0); return T2P_OK; }
   if (key == 29) { t2p::g_attn_strip = value != 0; return T2P_OK; }
+  if (key == 34) { set_gemm_a_norm(value != 0); return T2P_OK; }
   if (key == 32) { g_attn_merged = value != 0; return T2P_OK; }
   if (key == 33) { g_ffpo_merged = value != 0; return T2P_OK; }
   if (key == 30) { set_gemm_split_consts(value, 0); return T2P_OK; }

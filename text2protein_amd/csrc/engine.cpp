@@ -1290,16 +1290,31 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
   // head: GroupNorm -> SiLU -> conv3x3 (nf -> C), stored NCHW and divided by sigma[label]
   LayerScope head_scope("head,head," + std::to_string(L) + "," + std::to_string(final_ch_) + "," + std::to_string(Cx), s);
   void* a = nullptr;
-  T2P_TRY(group_norm(h, nullptr, head_norm_, 1e-6f, 1, 0, B, &a, s));
-  free_act(h);
   {
     GemmParams p;
-    p.dtype = dtype(); p.a_f32 = p.dtype == DT_F32; p.A0 = a; p.C0 = final_ch_; p.lda0 = final_ch_;
+    p.dtype = dtype(); p.a_f32 = p.dtype == DT_F32; p.C0 = final_ch_; p.lda0 = final_ch_;
     p.taps = 9; p.H = L; p.W = L;
     p.Bw = head_conv_.w; p.ldb = head_conv_.K; p.M = B * HW; p.N = Cx; p.bias_n = head_conv_.b;
     p.rows_per_batch = HW;
     p.C = out; p.c_f32 = 1; p.c_nchw = 1; p.row_scale = scale;
-    T2P_TRY(gemm(p, s));
+    p.A0 = h.p;
+    float* hstats = nullptr;
+    if (h.lowp && h.cstats && HW % 64 == 0 && gemm_applies_a_norm(p)) {
+      // GroupNorm + SiLU of the head inside the convolution's halo staging: the statistics come from the column sums of the last
+      // block's epilogue (one small launch), the 134 - 268 MB normalised copy of the map is never written
+      hstats = (float*)pool_.get((size_t)B * head_norm_.G * 2 * 4);
+      if (!hstats) return T2P_ERR_HIP;
+      T2P_TRY(launch_gn_finalize_cols(h.cstats, nullptr, h.C, 0, B, HW, head_norm_.G, 1e-6f, hstats, s));
+      p.an_stats = hstats; p.an_gamma = head_norm_.gamma; p.an_beta = head_norm_.beta; p.an_groups = head_norm_.G; p.an_silu = 1;
+      T2P_TRY(gemm(p, s));
+      pool_.put(hstats);
+      free_act(h);
+    } else {
+      T2P_TRY(group_norm(h, nullptr, head_norm_, 1e-6f, 1, 0, B, &a, s));
+      free_act(h);
+      p.A0 = a;
+      T2P_TRY(gemm(p, s));
+    }
   }
   pool_.put(a);
   pool_.put(scale);

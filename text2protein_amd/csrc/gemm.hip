@@ -2379,6 +2379,9 @@ struct ThinConvArgs {
   const void* x; const void* w; const float* bias; const float* row_scale; float* out;
   int B, H, W, Cin, Cout;
   long ldw;
+  // optional: x is the raw map; act(GroupNorm(x)) is applied while the halo is staged (out.0 + out.1 of the head, ncsnpp.py:211-216)
+  const float* gn_stats; const float* gn_gamma; const float* gn_beta;
+  int gn_groups, gn_silu;
 };
 
 template <typename TC, int CH>   // CH: channels staged per pass (32, 64 or 128)
@@ -2388,11 +2391,24 @@ __global__ __launch_bounds__(512) void thin_conv_kernel(const ThinConvArgs a) {
   constexpr int wrow = 9 * cb + 16;                         // padded weight row: lanes of a fragment read hit distinct banks
   constexpr int sw = (nchunk < 8 ? nchunk : 8) - 1;         // swizzle mask: stays inside the pixel's own chunks
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float nsc[256], nsh[256];                      // per-channel scale / shift of the fused GroupNorm (Cin <= 256)
   unsigned char* halo = smem;
   unsigned char* wl = smem + NPIX * cb;
   const int tid = threadIdx.x;
   const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
   const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, b = blockIdx.x / (tiles_x * tiles_y);
+  const bool norm = a.gn_stats != nullptr;
+  if (norm) {
+    // the same arithmetic as the separate GroupNorm-apply pass (gn_apply16_kernel): y = x * (rstd gamma) + (beta - mean rstd gamma)
+    if (tid < a.Cin) {
+      const int g = tid / (a.Cin / a.gn_groups);
+      const float mean = a.gn_stats[2 * (b * a.gn_groups + g)], rstd = a.gn_stats[2 * (b * a.gn_groups + g) + 1];
+      const float sc = rstd * a.gn_gamma[tid];
+      nsc[tid] = sc;
+      nsh[tid] = a.gn_beta[tid] - mean * sc;
+    }
+    __syncthreads();
+  }
   const int x0 = tx * TW, y0 = ty * TH;
   const TC* xb = (const TC*)a.x + (long)b * a.H * a.W * a.Cin;
   const int wave = tid >> 6, lane = tid & 63, r = lane & 15, g = lane >> 4;   // wave = pixel row of the tile
@@ -2403,8 +2419,22 @@ __global__ __launch_bounds__(512) void thin_conv_kernel(const ThinConvArgs a) {
     for (int i = tid; i < NPIX * nchunk; i += 512) {
       const int P = i / nchunk, j = i - P * nchunk;
       const int gy = y0 + P / WP - 1, gx = x0 + P % WP - 1;
-      u32x4_t v = {0u, 0u, 0u, 0u};                         // zero padding outside the map
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *(const u32x4_t*)(xb + ((long)gy * a.W + gx) * a.Cin + c0 + j * 8);
+      u32x4_t v = {0u, 0u, 0u, 0u};                         // zero padding outside the map (of the NORMALISED map: stays zero)
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        v = *(const u32x4_t*)(xb + ((long)gy * a.W + gx) * a.Cin + c0 + j * 8);
+        if (norm) {
+          union { u32x4_t u; TC e[8]; } in, o;
+          in.u = v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int c = c0 + j * 8 + e;
+            float y = to_f32(in.e[e]) * nsc[c] + nsh[c];
+            if (a.gn_silu) y = y * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(y * -1.44269504088896341f));
+            o.e[e] = from_f32<TC>(y);
+          }
+          v = o.u;
+        }
+      }
       *(u32x4_t*)(halo + P * cb + (((j & ~sw) | ((j ^ P) & sw)) << 4)) = v;
     }
     for (int i = tid; i < a.Cout * 9 * nchunk; i += 512) {
@@ -2442,7 +2472,9 @@ __global__ __launch_bounds__(512) void thin_conv_kernel(const ThinConvArgs a) {
 }
 
 static bool g_thin_conv = true;
+static bool g_a_norm = true;         // GroupNorm + SiLU of the head inside the head convolution's halo staging (plan switch 34)
 void set_gemm_thin_conv(bool on) { g_thin_conv = on; }
+void set_gemm_a_norm(bool on) { g_a_norm = on; }
 
 // true when launch_gemm(p) will take the thin-output kernel
 static bool thin_conv_eligible(const GemmParams& p) {
@@ -2451,6 +2483,8 @@ static bool thin_conv_eligible(const GemmParams& p) {
   if (p.N > 8 || (p.C0 != 32 && p.C0 != 64 && p.C0 != 128 && p.C0 != 256) || p.lda0 != p.C0) return false;
   return p.rows_per_batch == p.H * p.W && p.M % (p.H * p.W) == 0;
 }
+
+bool gemm_applies_a_norm(const GemmParams& p) { return g_thin_conv && g_a_norm && thin_conv_eligible(p) && p.C0 <= 256; }
 
 template <typename TC, int CH>
 static int launch_thin_conv_ch(const ThinConvArgs& a, hipStream_t stream) {
@@ -2466,6 +2500,7 @@ static int launch_thin_conv(const GemmParams& p, hipStream_t stream) {
   ThinConvArgs a;
   a.x = p.A0; a.w = p.Bw; a.bias = p.bias_n; a.row_scale = p.row_scale; a.out = (float*)p.C;
   a.B = p.M / (p.H * p.W); a.H = p.H; a.W = p.W; a.Cin = p.C0; a.Cout = p.N; a.ldw = p.ldb;
+  a.gn_stats = p.an_stats; a.gn_gamma = p.an_gamma; a.gn_beta = p.an_beta; a.gn_groups = p.an_groups; a.gn_silu = p.an_silu;
   if (p.C0 == 32) return launch_thin_conv_ch<TC, 32>(a, stream);
   if (p.C0 == 64) return launch_thin_conv_ch<TC, 64>(a, stream);
   return launch_thin_conv_ch<TC, 128>(a, stream);           // 128 or 256 channels: one or two passes
@@ -2513,6 +2548,12 @@ int launch_gemm(const GemmParams& p, hipStream_t stream) {
     T2P_REQUIRE(((uintptr_t)p.X0 % 16) == 0 && ((uintptr_t)p.X1 % 16) == 0 && p.ldx0 % 8 == 0 && p.ldx1 % 8 == 0, "shortcut segment: 16-byte aligned rows");
     T2P_REQUIRE(((long)p.M + 512) * std::max(p.ldx0, p.ldx1) * 2 < (1L << 31) - 64 && std::max(p.ldx0, p.ldx1) * 2 < (1L << 24), "shortcut segment: 32-bit offsets");
     T2P_REQUIRE(p.ldb >= 9L * (p.C0 + p.C1) + p.CX0 + p.CX1, "shortcut segment: weight rows hold 9 (C0 + C1) + CX0 + CX1 columns");
+  }
+  if (p.an_stats) {
+    GemmParams q = p;
+    q.an_stats = nullptr;
+    T2P_REQUIRE(p.an_gamma && p.an_beta && p.an_groups > 0 && p.C0 % p.an_groups == 0 && gemm_applies_a_norm(q),
+                "a GroupNorm of the A operand rides only on the thin-output head convolution (ask gemm_applies_a_norm)");
   }
   if (g_thin_conv && thin_conv_eligible(p)) {
     // the head convolution: timed as "conv on the register-staged kernel" by the profile hooks' kind 2

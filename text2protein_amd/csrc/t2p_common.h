@@ -149,6 +149,12 @@ struct GemmParams {
   int gn_groups = 0, gn_silu = 0;
   float gn_eps = 1e-6f;
   void* gn_out = nullptr;
+  // optional (ask gemm_applies_a_norm; the thin-output head convolution only): A0 holds the RAW map and the kernel applies
+  // act(GroupNorm(.)) while it stages its input halo -- an_stats [batch][groups][2] = (mean, rstd) per sample and group
+  const float* an_stats = nullptr;
+  const float* an_gamma = nullptr;
+  const float* an_beta = nullptr;
+  int an_groups = 0, an_silu = 0;
 };
 
 int launch_gemm(const GemmParams& p, hipStream_t stream);
@@ -158,6 +164,7 @@ bool gemm_fuses_geglu(const GemmParams& p);
 bool gemm_fuses_col_stats_lowp(const GemmParams& p);
 bool gemm_fuses_post_gn(const GemmParams& p, int groups);   // p without gn_*: would launch_gemm apply a following GroupNorm of `groups` groups?
 void set_gemm_post_gn(bool on);
+bool gemm_applies_a_norm(const GemmParams& p);      // p without an_*: would launch_gemm normalise A0 on the fly (head convolution)?
 void set_gemm_split_consts(int tiles, int target);
 void set_gemm_dma(bool on);
 void set_gemm_debug(int v);
@@ -167,6 +174,7 @@ void set_gemm_splitk(bool on);
 void set_gemm_force_nsplit(int v);
 void set_gemm_midsplit(bool on);
 void set_gemm_thin_conv(bool on);
+void set_gemm_a_norm(bool on);
 void set_gemm_conv_halo(bool on);
 void set_gemm_up4(bool on);
 void set_gemm_deep_ring(bool on);
