@@ -348,15 +348,17 @@ __global__ __launch_bounds__(256) void gn_apply_cols_kernel(GroupNormApplyArgs a
     red[0][tid >> 6][tid & 63] = s; red[1][tid >> 6][tid & 63] = q;
   }
   __syncthreads();
-  if (tid < 64 / cpg) {                                // one thread per group of the slab: cpg x 4 partial sums in a fixed order
-    double s = 0, q = 0;
-    for (int c = 0; c < cpg; ++c)
-      for (int w = 0; w < 4; ++w) { s += red[0][w][tid * cpg + c]; q += red[1][w][tid * cpg + c]; }
-    const double n = (double)HW * cpg, mean = s / n;
-    double var = q / n - mean * mean;
-    if (var < 0) var = 0;
-    gstat[0][tid] = (float)mean;
-    gstat[1][tid] = (float)(1.0 / sqrt(var + (double)a.eps));
+  if (tid < 64) {                                      // one lane per channel of the slab: its 4 partials, then the cpg channels of a
+    double s = (red[0][0][tid] + red[0][1][tid]) + (red[0][2][tid] + red[0][3][tid]);   // group through a fixed shuffle tree (cpg is a
+    double q = (red[1][0][tid] + red[1][1][tid]) + (red[1][2][tid] + red[1][3][tid]);   // power of two dividing 64): no serial chain
+    for (int sh = 1; sh < cpg; sh <<= 1) { s += __shfl_xor(s, sh, 64); q += __shfl_xor(q, sh, 64); }
+    if ((tid & (cpg - 1)) == 0) {
+      const double n = (double)HW * cpg, mean = s / n;
+      double var = q / n - mean * mean;
+      if (var < 0) var = 0;
+      gstat[0][tid / cpg] = (float)mean;
+      gstat[1][tid / cpg] = (float)(1.0 / sqrt(var + (double)a.eps));
+    }
   }
   __syncthreads();
   const int v = tid & 7, po = tid >> 3;                // 8 threads x 8 channels per pixel, 32 pixels per iteration
