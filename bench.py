@@ -19,6 +19,19 @@ PC step has identical shapes and cost, and one sample is exactly `num_scales` = 
 HBM when the timed region starts; the per-run text K/V projection is loop-invariant and untimed.
 Chains shard over ranks with no per-step collective (per-GPU batches, SURVEY 8(e) option A); one
 RCCL all_gather of the final samples closes the timed region.
+
+The JSON line (rank 0), beyond the contract's keys:
+  dispatches_per_step       device dispatches one PC step enqueues (graph nodes of a captured, unexecuted step)
+  roofline                  the dominant 3x3-convolution instantiation of the benchmarked precision against the dense MFMA peak:
+                            every GEMM launch of one PC step timed with HIP events on the launch stream (t2p_profile_*)
+  traffic_measured_in_run   false: roofline.traffic is the HBM byte count of the committed rocprofv3 --pmc passes of this
+                            command (profiles/), not a figure of this run
+  f32                       N = 1: the SAME workload on the exact-f32 engine (v_mfma_f32_32x32x2_f32, the reference's own
+                            arithmetic type): --f32-steps (10) steps after a warm-up step, with its own kernel roofline
+                            against the 157.3 TFLOP/s f32 matrix peak
+  cpu_baseline              N = 1: the oracle on the host cores, 2 chains x 3 PC steps after one warm-up step, scaled by N
+  cfg3                      N > 1: BASELINE configs[2] (cond_length.yml, 32 chains per GPU, length condition) measured by the same
+                            ranks with the same bracketing -- the workload the north star's 1000 samples/min is about
 """
 import argparse
 import ctypes as C
@@ -70,15 +83,21 @@ def parse():
 def cpu_baseline(cfg, sd, ctx_cpu, n_scales, k_steps=3):
     """The oracle (CPU restatement of the reference, checked against the reference's own runs) timed on this box's host
     cores on a bounded sample of the same workload: 2 chains, one warm-up PC step (thread pools,
-    allocator, caches), then k = 3 PC steps (6 score evaluations) timed; scaled by N PC steps per sample -- every step
-    has the same shapes and cost."""
+    allocator, caches), then k = 3 PC steps (6 score evaluations) timed (2 or 1 when the warm-up step shows a host on which
+    three would take more than about half a minute); scaled by N PC steps per sample -- every step has the same shapes and cost."""
     from oracle import t2p_oracle as O
     B = 2
     C_, L = cfg.data.num_channels, cfg.data.max_res_num
     g = torch.Generator().manual_seed(0)
     draw = lambda s: torch.randn(*s, generator=g)   # noqa: E731
     with torch.no_grad():
+        t0 = time.perf_counter()
         O.pc_sampler_ve(sd, cfg, (B, C_, L, L), ctx_cpu[:B], noise_fn=draw, n_steps_limit=1)          # warm-up step
+        warm = time.perf_counter() - t0
+        if warm > 25.0:            # a slow host: keep the leg bounded (about 30 s of CPU work), and say so in `sample`
+            k_steps = 1
+        elif warm > 12.0:
+            k_steps = 2
         t0 = time.perf_counter()
         O.pc_sampler_ve(sd, cfg, (B, C_, L, L), ctx_cpu[:B], noise_fn=draw, n_steps_limit=k_steps)
         dt = time.perf_counter() - t0
