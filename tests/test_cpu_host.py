@@ -296,3 +296,38 @@ def test_cli_refuses_mask_info_without_a_source(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "sampling_6d.py"), os.path.join(ROOT, "configs", "cond_length_inpainting.yml"),
                         "synthetic", "--mask_info", "1:5"], capture_output=True, text=True)
     assert r.returncode != 0 and "--inpaint_coords" in (r.stderr + r.stdout)
+
+
+def test_bench_line_carries_the_contract_keys():
+    """Static check of bench.py: the keys the driver and the review read are all written (no GPU here)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"', '"scaling"',
+                '"vs_baseline"', '"dtype"', '"data"', '"config"', '"workload"', '"roofline"', '"cpu_baseline"', '"bound"', '"achieved"',
+                '"peak"', '"frac"', '"traffic"', '"cores"', '"kind"', '"sample"', '"dispatches_per_step"', '"traffic_measured_in_run"',
+                '"f32"', '"cfg3"'):
+        assert key in src, key
+    assert 'out["roofline"]' in src and 'out["cpu_baseline"]' in src and "D.barrier(dist, dev)" in src and "D.max_over_ranks(" in src
+
+
+def test_vp_tables_follow_the_reference_arithmetic():
+    """sde_lib.VPSDE.vp_tables: the per-step tables of the fused VP loop restated from sde_lib.py:106-157, models/utils.py:138-157 and
+    sampling.py:184-186 with plain loops."""
+    import numpy as np
+    import torch
+    from text2protein_amd import sde_lib
+    N, eps = 40, 1e-3
+    sde = sde_lib.VPSDE(beta_min=0.1, beta_max=20.0, N=N)
+    label_f, scale, xc, alpha = sde.vp_tables(eps)
+    g = sde.g_table(eps)
+    lab = sde.label_table(eps)
+    ts = torch.linspace(1.0, eps, N)
+    betas = torch.linspace(0.1 / N, 20.0 / N, N)
+    alphas = 1.0 - betas
+    s1m = torch.sqrt(1.0 - torch.cumprod(alphas, 0))
+    for i in range(N):
+        t = ts[i]
+        k = int((t * (N - 1)).long())
+        assert int(lab[i]) == k and float(label_f[i]) == float(t * (N - 1))
+        assert float(scale[i]) == float(-1.0 / s1m[k])
+        assert abs(float(xc[i]) - float(1.0 - (torch.sqrt(alphas[k]) - 1.0))) < 1e-7
+        assert float(alpha[i]) == float(alphas[k]) and float(g[i]) == float(torch.sqrt(betas[k]))

@@ -301,3 +301,57 @@ def test_graph_replay_is_bit_identical_to_eager_steps():
         outs.append((x.clone(), xm.clone()))
     assert torch.isfinite(outs[0][0]).all()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_measurement_hooks_count_and_time_what_runs():
+    """t2p_sampler_count_dispatches (graph-node count of a captured, unexecuted step: the state does not move),
+    t2p_profile_layers_* (one timed record per block of the network, pre and head included) and t2p_debug_tap (a block's output of the
+    next evaluation in fp32) -- the hooks behind bench.py's dispatches_per_step / --layers and tools/exp_f16_layers.py."""
+    import ctypes as C
+    from text2protein_amd import _lib, synth, sde_lib, sampling
+    from text2protein_amd.arch import build_arch
+    from text2protein_amd.model import HipScoreModel
+    cfg = cfg_tiny()
+    cfg.device = "cuda"
+    lib = _lib.load()
+    model = HipScoreModel(cfg, dtype="f16")
+    model.load_state_dict(synth.synth_state_dict(cfg, 0))
+    ctx = synth.synth_context(2, 3, cfg.model.context_dim, 0).cuda()
+    model.set_context(ctx)
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=cfg.model.num_scales)
+    st = sampling.PCStepper(model, sde, 2, cfg.sampling.snr, seed=5)
+    x = sampling._device_randn_like(torch.empty(2, 5, 16, 16, device="cuda"), 9, 0) * 100.0
+    xm = torch.empty_like(x)
+    st.reset(0)
+    st.step(x, xm)                                       # fills the activation pool
+    torch.cuda.synchronize()
+    before = x.clone()
+    n1, n2 = st.count_dispatches(x, xm), st.count_dispatches(x, xm)
+    torch.cuda.synchronize()
+    assert n1 == n2 and n1 > 50 and torch.equal(x, before)          # nothing executed, same count twice
+    st.step(x, xm)                                       # the step index did not advance either: this is step 1, as scheduled
+    torch.cuda.synchronize()
+    assert torch.isfinite(x).all() and not torch.equal(x, before)
+    # per-block timing: two evaluations per PC step, each pre + every block + head
+    layers = list(build_arch(cfg).all_layers())
+    _lib.check(lib.t2p_profile_layers_begin())
+    st.step(x, xm)
+    buf = C.create_string_buffer(1 << 16)
+    _lib.check(lib.t2p_profile_layers_end(buf, len(buf)))
+    rows = [l.split(",") for l in buf.value.decode().strip().splitlines()]
+    assert len(rows) == 2 * (len(layers) + 2)
+    assert [r[0] for r in rows[:len(layers) + 2]] == ["pre"] + [l.prefix for l in layers] + ["head"]
+    assert all(len(r) == 6 and float(r[5]) > 0 for r in rows)
+    # tap: block 0's output of the next evaluation, fp32 NHWC; switching it off leaves the buffer alone
+    labels = torch.tensor([3, 1]).cuda()
+    tap = torch.zeros(2 * 16 * 16 * layers[0].out_ch, device="cuda")
+    sh = (C.c_int64 * 4)()
+    _lib.check(lib.t2p_debug_tap(0, C.c_void_p(tap.data_ptr()), tap.numel(), None))
+    out = model(x, labels, ctx)
+    _lib.check(lib.t2p_debug_tap(-1, None, 0, sh))
+    torch.cuda.synchronize()
+    assert list(sh)[:3] == [layers[0].out_ch, 16, 16] and float(tap.abs().sum()) > 0 and torch.isfinite(tap).all()
+    snapshot = tap.clone()
+    out2 = model(x, labels, ctx)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and torch.equal(tap, snapshot)
