@@ -175,6 +175,17 @@ int t2p_op_conv3x3_shortcut(int dtype, const void* a, const void* w, const float
 int t2p_op_conv3x3_groupnorm(int dtype, const void* a, const void* w, const float* bias, const float* bias_bn, const void* residual,
                              float alpha, int upsample, int groups, const float* gamma, const float* beta, float eps, int silu,
                              void* out, int out_f32, void* normed, float* col_stats, int batch, int H, int W, int C, int Cout, void* stream);
+/* a 3x3 convolution of an 8x8 or 4x4 map with everything ResnetBlockBigGANpp.forward (layers.py:303-327) does around it, in ONE
+ * launch with no second pass: a workgroup owns whole samples x whole GroupNorm groups (64 rows x 16 channels), so the norm that
+ * follows is applied on the spot.  a [batch][H][W][C], w [Cout][ldw] (K index = tap C + c, then CX0 + CX1 shortcut columns read
+ * at the output pixel from x0 | x1), residual [batch][H][W][Cout]: all in the 16-bit compute dtype; bias [Cout], bias_bn
+ * [batch][Cout] fp32.  out (optional, fp32 or 16-bit) = alpha (conv + shortcut + biases + residual); col_stats (optional, 8x8
+ * maps) its per-64-row column sums; normed (optional, 16-bit) = act(GroupNorm(out)) with `groups` groups of 8 or 16 channels.
+ * H = W in {4, 8}, batch H W % 64 == 0, C % 32 == 0, Cout % 16 == 0. */
+int t2p_op_small_conv_groupnorm(int dtype, const void* a, const void* w, int64_t ldw, const void* x0, int CX0, const void* x1, int CX1,
+                                const float* bias, const float* bias_bn, const void* residual, float alpha, void* out, int out_f32,
+                                float* col_stats, void* normed, int groups, const float* gamma, const float* beta, float eps, int silu,
+                                int batch, int H, int W, int C, int Cout, void* stream);
 /* the network's input convolution (pre_conv, ncsnpp.py:230: 3x3, C = 5 or 8 input channels -> nf) straight from the NCHW fp32
  * sample, in fp32 arithmetic: x [batch][C][H][W] fp32; w_tcn [3*3][C][nf] fp32 (tap-major); out NHWC [batch][H][W][nf] in
  * out_dtype.  col_stats (optional; W % 64 == 0, nf | 256): [batch H W / 64][nf][2] fp32 = (sum, sum of squares) of the fp32

@@ -214,10 +214,12 @@ def test_thousand_step_run_vs_reference(stem):
     assert res["f32"] < F32_RUN1000_TOL and res["f16"] < F16_TOL
 
 
-@pytest.mark.parametrize("stem", ["test_config", "cond_length"])
+@pytest.mark.parametrize("stem", ["cond_length"])
 def test_thousand_step_f16_within_tolerance(stem):
-    """The horizon the metric is quoted on: a complete 1000-step run at the cfg2 / cfg3 shape (2 chains), f16
-    engine against the exact-f32 engine on identical on-device Philox noise."""
+    """Secondary check of the horizon the metric is quoted on (the primary one is test_thousand_step_run_vs_reference, against the
+    reference's own runs): a complete 1000-step run at the cfg3 shape (2 chains, L = 128), f16 engine against the exact-f32 engine
+    on identical on-device Philox noise.  (The cfg2-shape variant of this test -- 4.9e-4 in rounds 2 and 3, profiles/r03_parity.json --
+    was retired in round 3: 112 s of a suite that has to fit the GPU box's time limit, for a figure the reference now pins.)"""
     from text2protein_amd import sampling, sde_lib, synth
     from text2protein_amd.conditions import synthetic_condition
     cfg, _, T, _ = _cfg(stem)
@@ -363,3 +365,36 @@ def test_merged_projections_match_the_reference(stem):
     print(f"{stem}: merged projections vs separate: rel-L2 = {d:.3e}; vs reference: separate {e0:.3e}, merged {e1:.3e}")
     _record(f"merged_projections_{stem}", {"merged_vs_separate": d, "separate_vs_reference": e0, "merged_vs_reference": e1})
     assert d < F16_SCORE_TOL and e1 < F16_SCORE_TOL and e1 < 1.1 * e0
+
+
+@pytest.mark.parametrize("stem", ["cond_length", "cond_length_inpainting", "test_config"])
+def test_small_map_convolution_kernel_matches_the_split_k_path(stem):
+    """Plan switch 36: the residual blocks of the 8x8 / 4x4 levels run each convolution with its shortcut segment, biases, residual and
+    the GroupNorm that follows in one launch (small_conv_gn_kernel) instead of split-K convolution + second pass.  Both plans against
+    the reference's full-size scores at the benchmark batch (the kernel is chosen where all its workgroups are resident at once)."""
+    from text2protein_amd import _lib, synth
+    cfg, B0, T, chains = _cfg(stem)
+    g = load_golden("full_" + stem)
+    sd = synth.synth_state_dict(cfg, 0)
+    x, labels, ctx = full_inputs(cfg, B0, T)
+    xs = torch.from_numpy(synth.normal(79, "filler_x", chains * x[0].numel()).reshape(chains, *x.shape[1:])).cuda() * 20.0
+    cs = synth.synth_context(chains, T, cfg.model.context_dim, 80).cuda()
+    ls = (torch.arange(chains, device="cuda") * 29 + 5) % cfg.model.num_scales
+    for i, s in enumerate((3, chains - 2)):
+        xs[s], cs[s], ls[s] = x[i].cuda(), ctx[i].cuda(), labels[i].cuda()
+    lib = _lib.load()
+    m16 = _model(cfg, sd, "f16")
+    outs = {}
+    try:
+        for sw in (0, 1):
+            _lib.check(lib.t2p_debug_set(36, sw))
+            outs[sw] = m16(xs, ls, cs).cpu()
+            assert torch.equal(outs[sw], m16(xs, ls, cs).cpu())
+    finally:
+        lib.t2p_debug_set(36, 1)
+    assert not torch.equal(outs[0], outs[1]), "the small-map kernel did not run"
+    d = rel_l2(outs[1], outs[0])
+    e = {sw: max(rel_l2(outs[sw][s], g["score"][i]) for i, s in enumerate((3, chains - 2))) for sw in (0, 1)}
+    print(f"{stem}: small-map convolution kernel vs split-K path: rel-L2 = {d:.3e}; vs reference: split-K {e[0]:.3e}, one launch {e[1]:.3e}")
+    _record(f"small_conv_{stem}", {"fused_vs_split_k": d, "split_k_vs_reference": e[0], "fused_vs_reference": e[1]})
+    assert d < F16_SCORE_TOL and e[1] < F16_SCORE_TOL and e[1] < 1.05 * e[0]

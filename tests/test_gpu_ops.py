@@ -691,3 +691,73 @@ def test_wide_head_attention_with_the_block_tail(lib, dt, B, n, d, r16, out_f32)
         if out_f32:                                   # and exactly consistent with the stored fp32 output
             o64 = out.cpu().double().reshape(B * n // 64, 64, d)
             assert rel_l2(cs.cpu(), torch.stack([o64.sum(1), (o64 * o64).sum(1)], -1)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [2, 1])
+@pytest.mark.parametrize("B,HWs,C,Cout,CX0,CX1,G,silu,with_res", [(8, 4, 256, 256, 0, 0, 32, 1, False), (4, 4, 512, 256, 256, 256, 32, 1, False),
+                                                                   (3, 8, 256, 256, 0, 0, 32, 1, True), (2, 8, 512, 512, 512, 512, 32, 0, False),
+                                                                   (4, 4, 64, 32, 0, 0, 4, 1, True), (1, 8, 1024, 512, 0, 0, 32, 1, False),
+                                                                   (2, 8, 256, 256, 256, 0, 32, 0, False)])
+def test_small_map_convolution_with_its_groupnorm(lib, dt, B, HWs, C, Cout, CX0, CX1, G, silu, with_res):
+    """small_conv_gn_kernel (t2p_op_small_conv_groupnorm): a 3x3 convolution of a 4x4 / 8x8 map + 1x1 shortcut segment + biases +
+    residual + the GroupNorm (+SiLU) that follows, one launch, against torch fp64 on the same 16-bit operands: the raw output in
+    fp32 and in 16 bits, its column statistics, the normalised map, and the norm-only call (raw output not wanted)."""
+    g = torch.Generator().manual_seed(B * 100 + C + CX0)
+    td = TDT[dt]
+    H = W = HWs
+    CX = CX0 + CX1
+    a = torch.randn(B, C, H, W, generator=g).to(td)
+    w1 = (torch.randn(Cout, C, 3, 3, generator=g) / (9 * C) ** 0.5).to(td)
+    x = torch.randn(B, max(CX, 1), H, W, generator=g).to(td)
+    w2 = (torch.randn(Cout, max(CX, 1), 1, 1, generator=g) / max(CX, 1) ** 0.5).to(td)
+    bias, tb = torch.randn(Cout, generator=g), torch.randn(B, Cout, generator=g)
+    res = torch.randn(B, Cout, H, W, generator=g).to(td) if with_res else None
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.3
+    alpha = 0.5 ** 0.5
+    raw = F.conv2d(a.double(), w1.double(), bias.double(), padding=1) + tb.double()[:, :, None, None]
+    if CX:
+        raw = raw + F.conv2d(x.double(), w2.double())
+    if with_res:
+        raw = raw + res.double()
+    raw = raw * alpha
+    normed = F.group_norm(raw, G, gamma.double(), beta.double(), eps=1e-6)
+    if silu:
+        normed = F.silu(normed)
+    wk = w1.permute(0, 2, 3, 1).reshape(Cout, 9 * C)
+    if CX:
+        wk = torch.cat([wk, w2.reshape(Cout, CX)], 1)
+    wk = dev(wk.contiguous())
+    xn = x.permute(0, 2, 3, 1)
+    x0 = dev(xn[..., :CX0]) if CX0 else None
+    x1 = dev(xn[..., CX0:]) if CX1 else None
+    for out_f32 in (1, 0, None):
+        out = None if out_f32 is None else torch.full((B, H, W, Cout), float("nan"), device="cuda", dtype=torch.float32 if out_f32 else td)
+        nrm = torch.full((B, H, W, Cout), float("nan"), device="cuda", dtype=td)
+        want_cs = H * W == 64 and out_f32 is not None
+        cs = torch.full((B * H * W // 64, Cout, 2), float("nan"), device="cuda") if want_cs else None
+        check(lib, lib.t2p_op_small_conv_groupnorm(dt, P(dev(a.permute(0, 2, 3, 1))), P(wk), wk.shape[1], P(x0) if CX0 else None, CX0,
+                                                   P(x1) if CX1 else None, CX1, P(dev(bias)), P(dev(tb)),
+                                                   P(dev(res.permute(0, 2, 3, 1))) if with_res else None, alpha, P(out) if out is not None else None,
+                                                   int(bool(out_f32)), P(cs) if want_cs else None, P(nrm), G, P(dev(gamma)), P(dev(beta)), 1e-6, silu,
+                                                   B, H, W, C, Cout, None))
+        torch.cuda.synchronize()
+        key = (dt, B, HWs, C, Cout, CX0, CX1, out_f32)
+        e_n = rel_l2(nrm.float().cpu(), normed.permute(0, 2, 3, 1))
+        assert e_n < (6e-4 if dt == 2 else 5e-3), (key, e_n)
+        if out is not None:
+            e_r = rel_l2(out.float().cpu(), raw.permute(0, 2, 3, 1))
+            assert e_r < (3e-6 if out_f32 else (6e-4 if dt == 2 else 5e-3)), (key, e_r)
+        if want_cs:
+            r64 = raw.permute(0, 2, 3, 1).reshape(B * H * W // 64, 64, Cout)
+            assert rel_l2(cs.cpu(), torch.stack([r64.sum(1), (r64 * r64).sum(1)], -1)) < 1e-5, key
+    # raw output only (no norm follows): normed = null
+    out = torch.full((B, H, W, Cout), float("nan"), device="cuda", dtype=td)
+    check(lib, lib.t2p_op_small_conv_groupnorm(dt, P(dev(a.permute(0, 2, 3, 1))), P(wk), wk.shape[1], P(x0) if CX0 else None, CX0,
+                                               P(x1) if CX1 else None, CX1, P(dev(bias)), P(dev(tb)),
+                                               P(dev(res.permute(0, 2, 3, 1))) if with_res else None, alpha, P(out), 0, None, None, 0, None, None,
+                                               1e-6, 0, B, H, W, C, Cout, None))
+    torch.cuda.synchronize()
+    assert rel_l2(out.float().cpu(), raw.permute(0, 2, 3, 1)) < (6e-4 if dt == 2 else 5e-3)
+    # shapes it does not cover are refused
+    assert lib.t2p_op_small_conv_groupnorm(dt, P(out), P(wk), wk.shape[1], None, 0, None, 0, None, None, None, 1.0, P(out), 0, None, None, 0, None,
+                                           None, 1e-6, 0, 1, 16, 16, C, Cout, None) != 0

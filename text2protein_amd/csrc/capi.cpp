@@ -264,6 +264,20 @@ int t2p_op_conv3x3_groupnorm(int dtype, const void* a, const void* w, const floa
   API_END
 }
 
+int t2p_op_small_conv_groupnorm(int dtype, const void* a, const void* w, int64_t ldw, const void* x0, int CX0, const void* x1, int CX1,
+                                const float* bias, const float* bias_bn, const void* residual, float alpha, void* out, int out_f32,
+                                float* col_stats, void* normed, int groups, const float* gamma, const float* beta, float eps, int silu,
+                                int batch, int H, int W, int C, int Cout, void* stream) {
+  API_BEGIN
+  SmallConvArgs s;
+  s.dtype = dtype; s.A = a; s.B = batch; s.H = H; s.W = W; s.C = C; s.N = Cout; s.Wt = w; s.ldw = ldw;
+  s.X0 = x0; s.CX0 = CX0; s.X1 = x1; s.CX1 = CX1; s.bias = bias; s.bias_bn = bias_bn; s.ld_bn = Cout; s.R = residual; s.alpha = alpha;
+  s.out = out; s.out_f32 = out_f32; s.col_stats = col_stats; s.normed = normed; s.gn_gamma = gamma; s.gn_beta = beta; s.groups = groups;
+  s.gn_silu = silu; s.gn_eps = eps;
+  return launch_small_conv_gn(s, (hipStream_t)stream);
+  API_END
+}
+
 int t2p_op_input_conv(const float* x, const float* w_tcn, const float* bias, void* out, int out_dtype, int batch, int C, int H, int W,
                       int nf, float* col_stats, void* stream) {
   API_BEGIN
@@ -488,6 +502,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 27) { t2p::g_gn_apply_cols = value != 0; return T2P_OK; }
   if (key == 28) { set_gemm_post_gn(value != 0); return T2P_OK; }
   if (key == 29) { t2p::g_attn_strip = value != 0; return T2P_OK; }
+  if (key == 36) { t2p::g_small_conv = value != 0; return T2P_OK; }
   if (key == 34) { set_gemm_a_norm(value != 0); return T2P_OK; }
   if (key == 32) { g_attn_merged = value != 0; return T2P_OK; }
   if (key == 33) { g_ffpo_merged = value != 0; return T2P_OK; }

@@ -793,6 +793,68 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
   // (a 16-bit residual stream is already in the GEMM operand format: no raw copy)
   const bool want_raw = g_raw_copies && L.has_conv2 && !L.down && dt != DT_F32 && !x.lowp;
   T2P_TRY(group_norm(x, skip, L.gn0, 1e-6f, 1, L.down, B, &a0, s, want_raw ? &xraw : nullptr));
+  // ---- 8x8 / 4x4 maps: each convolution with everything around it in ONE launch (small_conv_gn_kernel): a workgroup owns whole
+  // samples x whole groups, so GroupNorm_1 + SiLU (conv0) and the first norm of the block that follows (conv1) need no second
+  // pass; the 1x1 shortcut rides as an extra K segment, the identity shortcut as the residual
+  if (dt != DT_F32 && !L.up && (Ho * Wo == 16 || Ho * Wo == 64) && x.lowp && (!skip || skip->lowp) && (L.has_conv2 ? L.conv1x.w != nullptr : true)) {
+    SmallConvArgs c0;
+    c0.dtype = dt; c0.A = a0; c0.B = B; c0.H = Ho; c0.W = Wo; c0.C = Cin; c0.N = Cout; c0.Wt = L.conv0.w; c0.ldw = L.conv0.K;
+    c0.bias = L.conv0.b; c0.bias_bn = tb_ + L.temb_off; c0.ld_bn = tb_ld_;
+    c0.gn_gamma = L.gn1.gamma; c0.gn_beta = L.gn1.beta; c0.groups = L.gn1.G; c0.gn_silu = 1; c0.gn_eps = 1e-6f;
+    SmallConvArgs c1;
+    c1.dtype = dt; c1.B = B; c1.H = Ho; c1.W = Wo; c1.C = Cout; c1.N = Cout;
+    c1.alpha = cfg_.skip_rescale ? 0.70710678118654752440f : 1.f;
+    if (L.has_conv2) {
+      c1.Wt = L.conv1x.w; c1.ldw = L.conv1x.K; c1.bias = L.conv1x.b;
+      c1.CX0 = L.down ? Cin : x.C; c1.CX1 = (!L.down && skip) ? skip->C : 0;
+    } else {
+      c1.Wt = L.conv1.w; c1.ldw = L.conv1.K; c1.bias = L.conv1.b;
+    }
+    const bool olp = res_lowp();
+    if (hint.norm && olp && hint.norm->C == Cout) { c1.groups = hint.norm->G; c1.gn_silu = hint.silu; }
+    // (eligibility is a matter of shapes: probe with placeholders for the buffers allocated below)
+    c0.normed = a0; c1.A = a0; c1.out = a0; c1.normed = c1.groups ? a0 : nullptr;
+    c1.gn_gamma = c1.groups ? hint.norm->gamma : nullptr; c1.gn_beta = c1.groups ? hint.norm->beta : nullptr;
+    if (L.has_conv2) { c1.X0 = a0; c1.X1 = c1.CX1 ? a0 : nullptr; } else { c1.R = a0; }
+    if (small_conv_eligible(c0) && small_conv_eligible(c1)) {
+      POOL_GET(a1s, void*, (size_t)rows_out * Cout * dtype_size(dt));
+      c0.normed = a1s;
+      T2P_TRY(launch_small_conv_gn(c0, s));
+      pool_.put(a0);
+      void* xpooled = nullptr;
+      if (L.has_conv2) {
+        if (L.down) {                     // the shortcut of a down block reads the 2x2-averaged input (layers.py:313-315)
+          xpooled = pool_.get((size_t)rows_out * Cin * dtype_size(dt));
+          if (!xpooled) return T2P_ERR_HIP;
+          T2P_TRY(launch_pool2x2(x.p, xpooled, dt, B, x.H, x.W, Cin, s, x.lowp));
+          c1.X0 = xpooled;
+        } else {
+          c1.X0 = x.p;
+          c1.X1 = skip ? skip->p : nullptr;
+        }
+      } else {
+        c1.R = x.p;
+      }
+      POOL_GET(o, float*, (size_t)rows_out * Cout * (olp ? dtype_size(dt) : 4));
+      float* o_stats = nullptr;
+      void* pre = nullptr;
+      if (c1.groups) {
+        pre = pool_.get((size_t)rows_out * Cout * dtype_size(dt));
+        if (!pre) return T2P_ERR_HIP;
+      }
+      if (Ho * Wo == 64 && g_fuse_gn_stats) {
+        o_stats = (float*)pool_.get((size_t)(rows_out / 64) * Cout * 2 * 4);
+        if (!o_stats) return T2P_ERR_HIP;
+      }
+      c1.A = a1s; c1.out = o; c1.out_f32 = olp ? 0 : 1; c1.col_stats = o_stats; c1.normed = pre;
+      T2P_TRY(launch_small_conv_gn(c1, s));
+      pool_.put(a1s);
+      pool_.put(xpooled);
+      *out = Act{o, Cout, Ho, Wo, o_stats, olp};
+      out->pre_norm = pre; out->pre_for = pre ? hint.norm : nullptr; out->pre_silu = hint.silu;
+      return T2P_OK;
+    }
+  }
   float* h1_stats = nullptr;
   bool h1_lowp = false;
   void* a1_fused = nullptr;

@@ -137,6 +137,34 @@ struct StripEpilogue {
 int launch_attention_strip(int dtype, const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
                            int B, int n, int d, float scale, hipStream_t s, const StripEpilogue* ep = nullptr);
 
+// ---- 3x3 convolution of the 8x8 / 4x4 levels + the GroupNorm (+SiLU) that follows, one launch (smallconv.hip) ----------------------
+// out[row][n] = alpha (sum_{tap, c} A[pixel(row, tap)][c] Wt[n][tap C + c] + sum_c X[row][c] Wt[n][9 C + c] + bias[n]
+//                      + bias_bn[sample][n] + R[row][n]);   normed = act(GroupNorm(out))
+struct SmallConvArgs {
+  int dtype = DT_F16;
+  const void* A = nullptr;      // [B H W][C]     16-bit, dense
+  int B = 0, H = 0, W = 0, C = 0, N = 0;
+  const void* Wt = nullptr;     // [N][ldw]       16-bit, K index = tap * C + c, then the shortcut columns
+  long ldw = 0;
+  const void* X0 = nullptr; const void* X1 = nullptr;   // optional shortcut sources [B H W][CX0], [B H W][CX1] (16-bit, dense)
+  int CX0 = 0, CX1 = 0;
+  const float* bias = nullptr;      // [N]
+  const float* bias_bn = nullptr;   // [B][ld_bn] (time-embedding bias)
+  long ld_bn = 0;
+  const void* R = nullptr;          // residual [B H W][N], 16-bit
+  float alpha = 1.f;
+  void* out = nullptr;              // raw result [B H W][N], fp32 (out_f32) or 16-bit; may be null when `normed` is wanted only
+  int out_f32 = 0;
+  float* col_stats = nullptr;       // [B H W / 64][N][2] column sums / sums of squares of the raw fp32 values (8x8 maps)
+  void* normed = nullptr;           // act(GroupNorm(out)) [B H W][N], 16-bit; null = no norm
+  const float* gn_gamma = nullptr; const float* gn_beta = nullptr;
+  int groups = 0, gn_silu = 0;
+  float gn_eps = 1e-6f;
+};
+extern bool g_small_conv;
+bool small_conv_eligible(const SmallConvArgs& a);
+int launch_small_conv_gn(const SmallConvArgs& a, hipStream_t s);
+
 int launch_convert(const float* in, void* out, int dtype, long n, hipStream_t s);
 int launch_widen(const void* in, int dtype, float* out, long n, hipStream_t s);   // compute dtype -> fp32
 int launch_gather_label(const int* labels, const int* step_counter, const float* table, float* out, int B, int N,
