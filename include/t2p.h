@@ -189,7 +189,10 @@ int t2p_op_small_conv_groupnorm(int dtype, const void* a, const void* w, int64_t
 /* the network's input convolution (pre_conv, ncsnpp.py:230: 3x3, C = 5 or 8 input channels -> nf) straight from the NCHW fp32
  * sample, in fp32 arithmetic: x [batch][C][H][W] fp32; w_tcn [3*3][C][nf] fp32 (tap-major); out NHWC [batch][H][W][nf] in
  * out_dtype.  col_stats (optional; W % 64 == 0, nf | 256): [batch H W / 64][nf][2] fp32 = (sum, sum of squares) of the fp32
- * results per 64-pixel chunk and channel -- what the first GroupNorm needs, so that it does not re-read the tensor */
+ * results per 64-pixel chunk and channel -- what the first GroupNorm needs, so that it does not re-read the tensor.
+ * 16-bit out_dtype with W % 64 == 0, an even H and nf in {64, 128, 256}: the layer runs on the 16-bit matrix pipe with every fp32
+ * operand split into two f16 terms (fp32-class accuracy, ~2^-22; needs |x| < 65504 -- the engine takes this form for
+ * sigma_max <= 4096); the call then returns after the stream has drained (it prepares the split weights in a temporary) */
 int t2p_op_input_conv(const float* x, const float* w_tcn, const float* bias, void* out, int out_dtype, int batch, int C,
                       int H, int W, int nf, float* col_stats, void* stream);
 int t2p_op_groupnorm(const float* x0, const float* x1, int C0, int C1, int batch, int H, int W, int groups,

@@ -503,9 +503,12 @@ def test_input_conv_and_its_column_statistics(lib, C, nf, H, W):
     check(lib, lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(out32), 0, B, C, H, W, nf, None, None))
     torch.cuda.synchronize()
     assert rel_l2(out32.cpu(), ref) < 1e-6
-    # 16-bit output: on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, plan switch 26; W % 64 == 0) and on the FMA kernel
+    # 16-bit output: on the 16-bit matrix pipe with every fp32 operand split into two f16 terms (plan switch 38; W % 64 == 0 and
+    # an even H: the form the engine runs -- its column sums, taken before the rounding, are the evidence of fp32-class accuracy),
+    # on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, plan switch 26; W % 64 == 0) and on the FMA kernel
     try:
-        for sw in (1, 0):
+        for split, sw in ((1, 1), (0, 1), (0, 0)):
+            check(lib, lib.t2p_debug_set(38, split))
             check(lib, lib.t2p_debug_set(26, sw))
             out16 = torch.full((B, H, W, nf), float("nan"), device="cuda", dtype=torch.float16)
             check(lib, lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(out16), 2, B, C, H, W, nf, None, None))
@@ -524,6 +527,32 @@ def test_input_conv_and_its_column_statistics(lib, C, nf, H, W):
                 assert lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(out16), 2, B, C, H, W, nf, P(cs), None) != 0
     finally:
         lib.t2p_debug_set(26, 1)
+        lib.t2p_debug_set(38, 1)
+
+
+def test_input_conv_split_operands_keep_fp32_accuracy(lib):
+    """The split form of pre_conv (x = hi + lo / 2048 in f16, three partial products on v_mfma_f32_16x16x32_f16) at the
+    magnitudes of a VE run: a prior sample (sigma_max = 100), a late sample (values in [-1, 1] + 0.01 noise), exact zeros of a
+    masked region and tiny values below the f16 normal range.  Column sums (fp32, before the output rounding) against fp64."""
+    B, C, H, W, nf = 2, 5, 4, 128, 256
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, C, H, W, generator=g)
+    x[0] *= 100.0
+    x[1, :, :2] = x[1, :, :2].clamp(-1, 1) + 0.01 * torch.randn(C, 2, W, generator=g)
+    x[1, :, 2] = 0.0
+    x[1, :, 3] *= 1e-6
+    w = torch.randn(nf, C, 3, 3, generator=g) / (9 * C) ** 0.5
+    b = torch.randn(nf, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, 64, nf)
+    w_tcn = dev(w.permute(2, 3, 1, 0).reshape(9, C, nf).contiguous())
+    out = torch.full((B, H, W, nf), float("nan"), device="cuda", dtype=torch.float16)
+    cs = torch.full((B * H * W // 64, nf, 2), float("nan"), device="cuda")
+    check(lib, lib.t2p_op_input_conv(P(dev(x)), P(w_tcn), P(dev(b)), P(out), 2, B, C, H, W, nf, P(cs), None))
+    torch.cuda.synchronize()
+    per_chunk = (cs[..., 0].cpu().double() - ref.sum(1)).abs().amax(1) / ref.abs().sum(1).amax(1)
+    assert per_chunk.max() < 2e-6, per_chunk
+    assert rel_l2(cs[..., 1].cpu(), (ref ** 2).sum(1)) < 2e-6
+    assert rel_l2(out.float().cpu().reshape(-1, 64, nf), ref) < 3e-4
 
 
 @pytest.mark.parametrize("dt", [1, 2])

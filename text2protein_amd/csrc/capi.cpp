@@ -281,6 +281,16 @@ int t2p_op_small_conv_groupnorm(int dtype, const void* a, const void* w, int64_t
 int t2p_op_input_conv(const float* x, const float* w_tcn, const float* bias, void* out, int out_dtype, int batch, int C, int H, int W,
                       int nf, float* col_stats, void* stream) {
   API_BEGIN
+  if (pre_conv_split_ok(out_dtype, C, H, W, nf) && (!col_stats || pre_conv_fuses_col_stats(W, nf))) {
+    // the form the engine runs in 16-bit modes: split weights prepared on the fly here (the engine keeps them)
+    void* ws = nullptr;
+    T2P_HIP_CHECK(hipMalloc(&ws, pre_conv_split_weight_bytes(C, nf)));
+    int rc = launch_pre_conv_split_weights(w_tcn, ws, C, nf, (hipStream_t)stream);
+    if (rc == T2P_OK) rc = launch_pre_conv_split(x, ws, bias, out, out_dtype, batch, C, H, W, nf, (hipStream_t)stream, col_stats);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(ws);
+    return rc;
+  }
   return launch_pre_conv(x, w_tcn, bias, out, out_dtype, batch, C, H, W, nf, (hipStream_t)stream, col_stats);
   API_END
 }
@@ -503,6 +513,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 28) { set_gemm_post_gn(value != 0); return T2P_OK; }
   if (key == 29) { t2p::g_attn_strip = value != 0; return T2P_OK; }
   if (key == 36) { t2p::g_small_conv = value != 0; return T2P_OK; }
+  if (key == 38) { t2p::g_pre_conv_split = value != 0; return T2P_OK; }
   if (key == 34) { set_gemm_a_norm(value != 0); return T2P_OK; }
   if (key == 32) { g_attn_merged = value != 0; return T2P_OK; }
   if (key == 33) { g_ffpo_merged = value != 0; return T2P_OK; }

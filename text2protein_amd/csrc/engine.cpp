@@ -479,6 +479,15 @@ int Engine::finalize() {
     for (int n = 0; n < nf_; ++n)
       for (int k = 0; k < K9; ++k) mt[(size_t)k * nf_ + n] = m[(size_t)n * K9 + k];
     T2P_TRY(upload_f32(mt, &pre_conv_direct_));
+    // the same weights split into two f16 terms each, for the input convolution on the 16-bit matrix pipe (pre_conv_split_kernel).
+    // The split form needs |x| inside the f16 range: the state of a VE run stays within a few sigma_max
+    const int C = cfg_.num_channels;
+    if (dtype() != DT_F32 && (C == 5 || C == 8) && cfg_.sigma_max <= 4096.0) {
+      pre_conv_split_ = pool_.persistent(pre_conv_split_weight_bytes(C, nf_));
+      if (!pre_conv_split_) return T2P_ERR_HIP;
+      T2P_TRY(launch_pre_conv_split_weights(pre_conv_direct_, pre_conv_split_, C, nf_, nullptr));
+      T2P_HIP_CHECK(hipStreamSynchronize(nullptr));
+    }
   }
   std::vector<float> dw((size_t)temb_total_ * td), db(temb_total_);
   auto each_layer = [&](auto&& fn) -> int {
@@ -1301,7 +1310,10 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
       h0_stats = (float*)pool_.get((size_t)B * (HW / 64) * nf_ * 2 * 4);
       if (!h0_stats) return T2P_ERR_HIP;
     }
-    T2P_TRY(launch_pre_conv(x, pre_conv_direct_, pre_conv_.b, h0, hlp ? dtype() : DT_F32, B, Cx, L, L, nf_, s, h0_stats));
+    if (hlp && pre_conv_split_ && pre_conv_split_ok(dtype(), Cx, L, L, nf_))
+      T2P_TRY(launch_pre_conv_split(x, pre_conv_split_, pre_conv_.b, h0, dtype(), B, Cx, L, L, nf_, s, h0_stats));
+    else
+      T2P_TRY(launch_pre_conv(x, pre_conv_direct_, pre_conv_.b, h0, hlp ? dtype() : DT_F32, B, Cx, L, L, nf_, s, h0_stats));
   } else {
     POOL_GET(xin, float*, (size_t)B * HW * cpad_ * 4);
     T2P_TRY(launch_nchw_to_nhwc(x, xin, B, Cx, HW, cpad_, s));

@@ -159,6 +159,7 @@ class Engine {
   DevNorm head_norm_;
   int temb_total_ = 0;
   float* pre_conv_direct_ = nullptr;   // [nf][9][C] fp32 weights of the direct input convolution
+  void* pre_conv_split_ = nullptr;     // the same, each weight as two f16 terms (pre_conv_split_kernel; 16-bit modes)
   float* inv_sigma_ = nullptr;  // [N] fp32, 1 / sigmas[label] (descending sigmas)
   int ctx_B_ = 0, ctx_T_ = 0, ctx_Tpad_ = 0;
   void* splitk_ws_ = nullptr;

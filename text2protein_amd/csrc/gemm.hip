@@ -781,6 +781,9 @@ __host__ __device__ __forceinline__ bool reg_epilogue_ok(const GemmParams& p, co
   return true;
 }
 
+#ifndef T2P_C_AUX
+#define T2P_C_AUX 0          // cache policy of the register epilogue's 16-bit output stores (measurement variants: 2 nt, 16 sc1, 17 sc0 sc1)
+#endif
 template <typename TC, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc16)[8][4], const int m0, const int n0, const int z0,
                                              const int z1, const int nsplit, const int ks, const int dbg) {
@@ -949,7 +952,7 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (f32x4_t){w[4], w[5], w[6], w[7]}), rC, off == DMA_OOB ? DMA_OOB : off + 16, 0, 0);
       } else {
         __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){pack2<TC>(w[0], w[1]), pack2<TC>(w[2], w[3]), pack2<TC>(w[4], w[5]), pack2<TC>(w[6], w[7])},
-                                               rC, off, 0, 0);
+                                               rC, off, 0, T2P_C_AUX);
       }
     }
   };

@@ -1027,6 +1027,233 @@ __global__ __launch_bounds__(256, 2) void pre_conv_mfma_kernel(const float* x, c
   }
 }
 
+// ---- the input convolution on the 16-bit matrix pipe with fp32-class accuracy (16-bit modes) ------------------------------
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the 16-bit rate: the kernel above is bound by the matrix pipe (12 GFLOP at 157 TFLOP/s
+// peak; 169 us at cfg2) although the layer only has to write its output once (268 MB: ~55 us).  Here every fp32 operand is
+// split into two f16 terms, v = hi + lo' / 2048 with hi = f16(v) and lo' = f16((v - hi) * 2048) (the scaling keeps lo' a normal
+// number; |v| < 2^-14 has hi = 0), and x * w ~ x_hi w_hi + (x_lo' w_hi + x_hi w_lo') / 2048 -- the dropped term and the two
+// roundings are ~2^-22 relative, the class of the fp32 kernels.  The three partial products are K segments of ONE f16 GEMM with
+// two accumulators (v_mfma_f32_16x16x32_f16):
+//   A'[pixel][0 .. K) = x_hi,  [KH .. KH + K) = x_lo',  [KH + KE .. KH + KE + K) = x_hi        (KH = K rounded up to 32, KE to 2)
+//   B'[chan ][0 .. K) = w_hi,  [KH .. KH + K) = w_hi,   [KH + KE .. KH + KE + K) = w_lo'       (pre_conv_split_weights_kernel)
+//   out = acc_h (K-steps below KH) + acc_l / 2048 + bias
+// A workgroup (4 wavefronts) walks tiles of 2 image rows x 64 pixels: the fp32 input patch (4 x 66 x C) -> LDS, the im2col rows
+// A' built from it (two k per thread and store: conflict-free), then wave w multiplies all 128 pixels by ITS nf / 4 channels,
+// whose B' fragments stay in registers for the whole launch.  A lane ends with 8 consecutive channels of a pixel per pair of
+// column tiles (the channel order of the tiles is chosen for that): 16-byte stores, whole 64-byte segments per pixel and wave.
+// GroupNorm column statistics: a 64-pixel chunk is the four row tiles of one image row of the tile (fp32 values, before rounding).
+typedef _Float16 ph8 __attribute__((ext_vector_type(8)));
+typedef float pf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float prow16_sum(float x) {        // sum over the 16 lanes of a DPP row, fixed order
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, false));
+  return x;
+}
+__host__ __device__ inline void split_f16(float v, _Float16& hi, _Float16& lo) {
+  hi = fabsf(v) < 6.103515625e-05f ? (_Float16)0.f : (_Float16)v;
+  lo = (_Float16)((v - (float)hi) * 2048.f);
+}
+template <int C> struct PreSplit {
+  static constexpr int K = 9 * C, KE = (K + 1) & ~1, KH = (K + 31) & ~31, KP = KH + ((2 * KE + 31) & ~31);   // 45: 64 + 96; 72: 96 + 160
+  static constexpr int NSH = KH / 32, NS = KP / 32;
+  static constexpr int RS = KP * 2 + 16;                   // LDS bytes per pixel row of A' (an odd number of 16-byte units)
+};
+// channel of column c (0 .. 15) of column tile j of a wave that owns 16 NCT channels from `base`
+template <int NCT> __host__ __device__ inline int presplit_chan(int base, int j, int c) {
+  if (NCT == 1) return base + c;
+  return base + 32 * (j >> 1) + 8 * (c >> 2) + 4 * (j & 1) + (c & 3);
+}
+// w [K][nf] fp32 (tap-major: k = tap * C + c) -> B' [nf][KP] f16
+template <int C>
+__global__ void pre_conv_split_weights_kernel(const float* w, _Float16* out, int nf) {
+  typedef PreSplit<C> P;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nf * P::KP) return;
+  const int ch = i / P::KP, kk = i - ch * P::KP;
+  int k = -1, part = 0;
+  if (kk < P::K) { k = kk; part = 0; }
+  else if (kk >= P::KH && kk < P::KH + P::K) { k = kk - P::KH; part = 0; }
+  else if (kk >= P::KH + P::KE && kk < P::KH + P::KE + P::K) { k = kk - P::KH - P::KE; part = 1; }
+  _Float16 hi = (_Float16)0.f, lo = (_Float16)0.f;
+  if (k >= 0) split_f16(w[(long)k * nf + ch], hi, lo);
+  out[i] = k < 0 ? (_Float16)0.f : (part ? lo : hi);
+}
+
+template <int C, int NCT, typename TO>
+__global__ __launch_bounds__(256) void pre_conv_split_kernel(const float* x, const _Float16* wsplit, const float* bias, TO* out, int B, int H,
+                                                             int W, int nf, float* cstats, int ntiles) {
+  typedef PreSplit<C> P;
+  constexpr int K = P::K, KE = P::KE, KH = P::KH, KP = P::KP, NS = P::NS, NSH = P::NSH, RS = P::RS;
+  constexpr int PW = 66, PR = 4, NPAIR = KE / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char ssm[];
+  unsigned char* arow = ssm;                                  // [128 pixels][RS]
+  float* patch = (float*)(ssm + 128 * RS);                    // [C][PR][PW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g4 = lane >> 4;
+  const int segs = W / 64, rpairs = H / 2;
+  const int cbase = wave * 16 * NCT;
+  // this wave's weights: NCT column tiles x NS K-steps, resident
+  ph8 bf[NCT][NS];
+#pragma unroll
+  for (int j = 0; j < NCT; ++j) {
+    const _Float16* wr = wsplit + (long)presplit_chan<NCT>(cbase, j, l16) * KP + 8 * g4;
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2) bf[j][s2] = *(const ph8*)(wr + 32 * s2);
+  }
+  // this lane's output channels: column tile j, accumulator element e -> presplit_chan(cbase, j, 4 g4 + e)
+  float bv[NCT][4];
+#pragma unroll
+  for (int j = 0; j < NCT; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[j][e] = bias[presplit_chan<NCT>(cbase, j, 4 * g4 + e)];
+  // the padding of A' is written once: [K, KH), [KH + K, KH + KE), [KH + KE + K, KP) of every row (two k per store)
+  for (int i = tid; i < 128 * (KP / 2); i += 256) {
+    const int px = i / (KP / 2), kp = i - px * (KP / 2);
+    *(unsigned*)(arow + px * RS + kp * 4) = 0u;
+  }
+  // the patch of the NEXT tile is requested (into registers) before this tile's matrix work and stored after it: the global
+  // latency of the only input stream is off the critical path
+  constexpr int NPRE = (C * PR * PW + 255) / 256;
+  float pre[NPRE];
+  auto fetch = [&](int tile) {
+    const int seg = tile % segs, rp = (tile / segs) % rpairs, b = tile / (segs * rpairs);
+    const int x0 = seg * 64, y0 = rp * 2;
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+      const int i = tid + 256 * j;
+      const int c = i / (PR * PW), r = (i / PW) % PR, col = i % PW;
+      const int sy = y0 + r - 1, sx = x0 + col - 1;
+      pre[j] = (i < C * PR * PW && sy >= 0 && sy < H && sx >= 0 && sx < W) ? x[(((long)b * C + c) * H + sy) * W + sx] : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int seg = tile % segs, rp = (tile / segs) % rpairs, b = tile / (segs * rpairs);
+    const int x0 = seg * 64, y0 = rp * 2;
+    __syncthreads();                                          // the previous tile's A' and patch are no longer read
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j)
+      if (tid + 256 * j < C * PR * PW) patch[tid + 256 * j] = pre[j];
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+    for (int i = tid; i < 128 * NPAIR; i += 256) {
+      const int px = i / NPAIR, kp = i - px * NPAIR;
+      const int r = px >> 6, col = px & 63;
+      _Float16 h0, l0, h1 = (_Float16)0.f, l1 = (_Float16)0.f;
+      {
+        const int k = 2 * kp, tap = k / C, c = k - tap * C;
+        split_f16(patch[(c * PR + r + tap / 3) * PW + col + tap % 3], h0, l0);
+      }
+      if (2 * kp + 1 < K) {
+        const int k = 2 * kp + 1, tap = k / C, c = k - tap * C;
+        split_f16(patch[(c * PR + r + tap / 3) * PW + col + tap % 3], h1, l1);
+      }
+      typedef _Float16 ph2 __attribute__((ext_vector_type(2)));
+      const unsigned hh = __builtin_bit_cast(unsigned, (ph2){h0, h1}), ll = __builtin_bit_cast(unsigned, (ph2){l0, l1});
+      unsigned char* row = arow + px * RS + kp * 4;
+      *(unsigned*)row = hh;
+      *(unsigned*)(row + KH * 2) = ll;
+      *(unsigned*)(row + (KH + KE) * 2) = hh;
+    }
+    __syncthreads();
+    float ssum[NCT][4], ssq[NCT][4];
+#pragma unroll 1
+    for (int rt = 0; rt < 8; ++rt) {
+      if ((rt & 3) == 0) {
+#pragma unroll
+        for (int j = 0; j < NCT; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ssum[j][e] = 0.f; ssq[j][e] = 0.f; }
+      }
+      const unsigned char* ar = arow + (rt * 16 + l16) * RS + g4 * 16;
+      ph8 af[NS];
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) af[s2] = *(const ph8*)(ar + s2 * 64);
+      pf4 ah[NCT], al[NCT];
+#pragma unroll
+      for (int j = 0; j < NCT; ++j) { ah[j] = pf4{0.f, 0.f, 0.f, 0.f}; al[j] = pf4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) {
+          if (s2 < NSH) ah[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][s2], af[s2], ah[j], 0, 0, 0);
+          else al[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][s2], af[s2], al[j], 0, 0, 0);
+        }
+      const int px = rt * 16 + l16;
+      TO* dst = out + (((long)b * H + y0 + (px >> 6)) * W + x0 + (px & 63)) * nf;
+      float v[NCT][4];
+#pragma unroll
+      for (int j = 0; j < NCT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t = ah[j][e] + al[j][e] * (1.f / 2048.f) + bv[j][e];
+          v[j][e] = t;
+          ssum[j][e] += t; ssq[j][e] += t * t;
+        }
+      if constexpr (NCT == 1) {
+        union { TO e[4]; uint2 u; } o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.e[e] = from_f32<TO>(v[0][e]);
+        *(uint2*)(dst + cbase + 4 * g4) = o.u;
+      } else {
+#pragma unroll
+        for (int jp = 0; jp < NCT / 2; ++jp) {
+          union { TO e[8]; uint4 u; } o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o.e[e] = from_f32<TO>(v[2 * jp][e]); o.e[4 + e] = from_f32<TO>(v[2 * jp + 1][e]); }
+          *(uint4*)(dst + cbase + 32 * jp + 8 * g4) = o.u;
+        }
+      }
+      if (cstats && (rt & 3) == 3) {
+        const long chunk = (((long)b * H + y0 + (rt >> 2)) * W + x0) >> 6;
+#pragma unroll
+        for (int j = 0; j < NCT; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float s0 = prow16_sum(ssum[j][e]), s1 = prow16_sum(ssq[j][e]);
+            if (l16 == 0) *(float2*)(cstats + (chunk * nf + presplit_chan<NCT>(cbase, j, 4 * g4 + e)) * 2) = make_float2(s0, s1);
+          }
+      }
+    }
+  }
+}
+
+bool g_pre_conv_split = true;     // plan switch 38
+size_t pre_conv_split_weight_bytes(int C, int nf) { return (size_t)nf * (C == 5 ? PreSplit<5>::KP : PreSplit<8>::KP) * 2; }
+bool pre_conv_split_ok(int out_dtype, int C, int H, int W, int nf) {
+  return g_pre_conv_split && out_dtype != DT_F32 && (C == 5 || C == 8) && W % 64 == 0 && H % 2 == 0 && (nf == 256 || nf == 128 || nf == 64);
+}
+int launch_pre_conv_split_weights(const float* w, void* wsplit, int C, int nf, hipStream_t s) {
+  T2P_REQUIRE(w && wsplit && (C == 5 || C == 8), "pre_conv_split_weights arguments");
+  const int n = nf * (C == 5 ? PreSplit<5>::KP : PreSplit<8>::KP);
+  if (C == 5) hipLaunchKernelGGL((pre_conv_split_weights_kernel<5>), dim3((n + 255) / 256), dim3(256), 0, s, w, (_Float16*)wsplit, nf);
+  else hipLaunchKernelGGL((pre_conv_split_weights_kernel<8>), dim3((n + 255) / 256), dim3(256), 0, s, w, (_Float16*)wsplit, nf);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+int launch_pre_conv_split(const float* x, const void* wsplit, const float* bias, void* out, int out_dtype, int B, int C, int H, int W, int nf,
+                          hipStream_t s, float* cstats) {
+  T2P_REQUIRE(x && wsplit && bias && out && pre_conv_split_ok(out_dtype, C, H, W, nf), "pre_conv_split arguments");
+  const int ntiles = B * (H / 2) * (W / 64);
+  const int grid = std::min(ntiles, 1024);
+  const int smem = 128 * (C == 5 ? PreSplit<5>::RS : PreSplit<8>::RS) + C * 4 * 66 * 4;
+#define T2P_PRES(CC, NCT, TT)                                                                         \
+  {                                                                                                   \
+    auto kern = pre_conv_split_kernel<CC, NCT, TT>;                                                   \
+    T2P_TRY(ensure_dynamic_lds((const void*)kern, smem));                                             \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, x, (const _Float16*)wsplit, bias, (TT*)out, B, H, W, nf, cstats, ntiles); \
+  }
+#define T2P_PRES_C(NCT, TT) if (C == 5) T2P_PRES(5, NCT, TT) else T2P_PRES(8, NCT, TT)
+#define T2P_PRES_T(NCT) if (out_dtype == DT_F16) { T2P_PRES_C(NCT, f16_t) } else { T2P_PRES_C(NCT, bf16_t) }
+  if (nf == 256) { T2P_PRES_T(4) } else if (nf == 128) { T2P_PRES_T(2) } else { T2P_PRES_T(1) }
+#undef T2P_PRES_T
+#undef T2P_PRES_C
+#undef T2P_PRES
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
 bool g_pre_conv_mfma = true;      // plan switch 26
 static bool pre_conv_mfma_ok(int out_dtype, int C, int W, int nf) {
   return g_pre_conv_mfma && out_dtype != DT_F32 && (C == 5 || C == 8) && W % 64 == 0 && (nf == 256 || nf == 128 || nf == 64);

@@ -66,6 +66,14 @@ int launch_pool2x2(const float* x, void* out, int dtype, int B, int H, int W, in
 int launch_pre_conv(const float* x, const float* w, const float* bias, void* out, int out_dtype, int B, int C, int H, int W, int nf,
                     hipStream_t s, float* cstats = nullptr);
 bool pre_conv_fuses_col_stats(int W, int nf);
+// the same layer on the 16-bit matrix pipe with every fp32 operand split into two f16 terms (fp32-class accuracy, plan switch 38):
+// wsplit = the weights in that form (pre_conv_split_weight_bytes bytes, written by launch_pre_conv_split_weights from w [9][C][nf])
+extern bool g_pre_conv_split;
+size_t pre_conv_split_weight_bytes(int C, int nf);
+bool pre_conv_split_ok(int out_dtype, int C, int H, int W, int nf);
+int launch_pre_conv_split_weights(const float* w, void* wsplit, int C, int nf, hipStream_t s);
+int launch_pre_conv_split(const float* x, const void* wsplit, const float* bias, void* out, int out_dtype, int B, int C, int H, int W, int nf,
+                          hipStream_t s, float* cstats = nullptr);
 
 // ---- NCHW fp32 (B,C,L,L) -> NHWC fp32 [B][L*L][Cpad], zero padded channels -----------------------
 int launch_nchw_to_nhwc(const float* x, float* out, int B, int C, int HW, int Cpad, hipStream_t s);

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--geom", type=int, default=0)
     ap.add_argument("--ring", type=int, default=0)
     ap.add_argument("--no-dma", action="store_true")
-    ap.add_argument("--c16", action="store_true", help="1x1 GEMM: compute-dtype output instead of fp32")
+    ap.add_argument("--c16", action="store_true", help="compute-dtype output instead of fp32")
     ap.add_argument("--nsplit", type=int, default=0, help="force this split-K factor (conv only; attaches a workspace)")
     ap.add_argument("--halo", type=int, default=1, help="3x3 convolutions on the LDS-halo kernel where eligible (plan switch 16)")
     ap.add_argument("--ablation", action="store_true", help="use the -DT2P_ABLATION library (needed for --dbg bits that skip work)")
@@ -51,7 +51,9 @@ def main():
     P = lambda t: C.c_void_p(t.data_ptr())
 
     def run():
-        if a.taps == 9:
+        if a.taps == 9 and a.c16:     # 16-bit output, as inside the network (the shortcut operator without a shortcut segment)
+            rc = lib.t2p_op_conv3x3_shortcut(dt, P(x), P(w), P(b), None, 0, None, 0, C.c_float(1.0), P(out), 0, a.B, a.H, a.W, a.cin, a.cout, None)
+        elif a.taps == 9:
             rc = lib.t2p_op_conv3x3(dt, P(x), int(dt == 0), P(w), P(b), P(out), a.B, a.H, a.W, a.cin, a.cout, 0, None)
         else:
             M = a.B * a.H * a.W
