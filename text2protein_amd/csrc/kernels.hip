@@ -1112,6 +1112,19 @@ __global__ __launch_bounds__(256) void pre_conv_split_kernel(const float* x, con
     const int px = i / (KP / 2), kp = i - px * (KP / 2);
     *(unsigned*)(arow + px * RS + kp * 4) = 0u;
   }
+  // this lane's k pairs: kp = (lane & 31) + 32 q; patch offset of k = tap * C + c at output pixel (r, col): (c PR + r + dy) PW + col + dx
+  constexpr int NKQ = (NPAIR + 31) / 32;
+  int kq_off0[NKQ], kq_off1[NKQ];
+#pragma unroll
+  for (int q = 0; q < NKQ; ++q) {
+    const int kp = (lane & 31) + 32 * q;
+    kq_off0[q] = kq_off1[q] = -1;
+    if (kp < NPAIR) {
+      const int k0 = 2 * kp, t0 = k0 / C, c0 = k0 - t0 * C;
+      kq_off0[q] = (c0 * PR + t0 / 3) * PW + t0 % 3;
+      if (k0 + 1 < K) { const int k1 = k0 + 1, t1 = k1 / C, c1 = k1 - t1 * C; kq_off1[q] = (c1 * PR + t1 / 3) * PW + t1 % 3; }
+    }
+  }
   // the patch of the NEXT tile is requested (into registers) before this tile's matrix work and stored after it: the global
   // latency of the only input stream is off the critical path
   constexpr int NPRE = (C * PR * PW + 255) / 256;
@@ -1137,24 +1150,25 @@ __global__ __launch_bounds__(256) void pre_conv_split_kernel(const float* x, con
       if (tid + 256 * j < C * PR * PW) patch[tid + 256 * j] = pre[j];
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
-    for (int i = tid; i < 128 * NPAIR; i += 256) {
-      const int px = i / NPAIR, kp = i - px * NPAIR;
-      const int r = px >> 6, col = px & 63;
-      _Float16 h0, l0, h1 = (_Float16)0.f, l1 = (_Float16)0.f;
-      {
-        const int k = 2 * kp, tap = k / C, c = k - tap * C;
-        split_f16(patch[(c * PR + r + tap / 3) * PW + col + tap % 3], h0, l0);
+    // A': a lane keeps its pair of k (patch offsets fixed for the whole launch), a wave walks its 32 pixels two per instruction:
+    // consecutive lanes store consecutive dwords of a row (conflict-free), no index arithmetic beyond the pixel's patch position
+#pragma unroll
+    for (int q = 0; q < NKQ; ++q) {
+      if (kq_off0[q] < 0) continue;
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int px = wave * 32 + 2 * it + (lane >> 5);
+        const int pb = (px >> 6) * PW + (px & 63);
+        _Float16 h0, l0, h1 = (_Float16)0.f, l1 = (_Float16)0.f;
+        split_f16(patch[kq_off0[q] + pb], h0, l0);
+        if (kq_off1[q] >= 0) split_f16(patch[kq_off1[q] + pb], h1, l1);
+        typedef _Float16 ph2 __attribute__((ext_vector_type(2)));
+        const unsigned hh = __builtin_bit_cast(unsigned, (ph2){h0, h1}), ll = __builtin_bit_cast(unsigned, (ph2){l0, l1});
+        unsigned char* row = arow + px * RS + ((lane & 31) + 32 * q) * 4;
+        *(unsigned*)row = hh;
+        *(unsigned*)(row + KH * 2) = ll;
+        *(unsigned*)(row + (KH + KE) * 2) = hh;
       }
-      if (2 * kp + 1 < K) {
-        const int k = 2 * kp + 1, tap = k / C, c = k - tap * C;
-        split_f16(patch[(c * PR + r + tap / 3) * PW + col + tap % 3], h1, l1);
-      }
-      typedef _Float16 ph2 __attribute__((ext_vector_type(2)));
-      const unsigned hh = __builtin_bit_cast(unsigned, (ph2){h0, h1}), ll = __builtin_bit_cast(unsigned, (ph2){l0, l1});
-      unsigned char* row = arow + px * RS + kp * 4;
-      *(unsigned*)row = hh;
-      *(unsigned*)(row + KH * 2) = ll;
-      *(unsigned*)(row + (KH + KE) * 2) = hh;
     }
     __syncthreads();
     float ssum[NCT][4], ssq[NCT][4];
