@@ -401,3 +401,36 @@ def test_small_map_convolution_kernel_matches_the_split_k_path(stem):
     print(f"{stem}: small-map convolution kernel vs split-K path: rel-L2 = {d:.3e}; vs reference: split-K {e[0]:.3e}, one launch {e[1]:.3e}")
     _record(f"small_conv_{stem}", {"fused_vs_split_k": d, "split_k_vs_reference": e[0], "fused_vs_reference": e[1]})
     assert d < F16_SCORE_TOL and e[1] < F16_SCORE_TOL and e[1] < 1.05 * e[0]
+
+
+@pytest.mark.parametrize("stem", ["cond_length", "cond_length_inpainting"])
+def test_spatial_transformer_row_chains_match_separate_launches(stem):
+    """Plan switch 39: GroupNorm -> proj_in -> LayerNorm_1 -> q | k | v of every SpatialTransformer block of the C = 256 configurations
+    as one launch over 32-row blocks (st_entry_kernel) instead of four.  Both plans against the reference's full-size scores at the
+    benchmark batch."""
+    from text2protein_amd import _lib, synth
+    cfg, B0, T, chains = _cfg(stem)
+    g = load_golden("full_" + stem)
+    sd = synth.synth_state_dict(cfg, 0)
+    x, labels, ctx = full_inputs(cfg, B0, T)
+    xs = torch.from_numpy(synth.normal(79, "filler_x", chains * x[0].numel()).reshape(chains, *x.shape[1:])).cuda() * 20.0
+    cs = synth.synth_context(chains, T, cfg.model.context_dim, 80).cuda()
+    ls = (torch.arange(chains, device="cuda") * 29 + 5) % cfg.model.num_scales
+    for i, s in enumerate((3, chains - 2)):
+        xs[s], cs[s], ls[s] = x[i].cuda(), ctx[i].cuda(), labels[i].cuda()
+    lib = _lib.load()
+    m16 = _model(cfg, sd, "f16")
+    outs = {}
+    try:
+        for sw in (0, 1):
+            _lib.check(lib.t2p_debug_set(39, sw))
+            outs[sw] = m16(xs, ls, cs).cpu()
+            assert torch.equal(outs[sw], m16(xs, ls, cs).cpu())
+    finally:
+        lib.t2p_debug_set(39, 1)
+    assert not torch.equal(outs[0], outs[1]), "the row-chain kernel did not run"
+    d = rel_l2(outs[1], outs[0])
+    e = {sw: max(rel_l2(outs[sw][s], g["score"][i]) for i, s in enumerate((3, chains - 2))) for sw in (0, 1)}
+    print(f"{stem}: SpatialTransformer row chains vs separate launches: rel-L2 = {d:.3e}; vs reference: separate {e[0]:.3e}, chains {e[1]:.3e}")
+    _record(f"st_chains_{stem}", {"fused_vs_separate": d, "separate_vs_reference": e[0], "fused_vs_reference": e[1]})
+    assert d < F16_SCORE_TOL and e[1] < F16_SCORE_TOL and e[1] < 1.05 * e[0]

@@ -278,6 +278,19 @@ int t2p_op_small_conv_groupnorm(int dtype, const void* a, const void* w, int64_t
   API_END
 }
 
+int t2p_op_st_entry(int dtype, const void* x, const float* col_stats, int groups, const float* gn_gamma, const float* gn_beta, float gn_eps,
+                    const void* w_in, const float* b_in, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_qkv,
+                    void* t, void* qkv, int batch, int n, int C, void* stream) {
+  API_BEGIN
+  StEntryArgs e;
+  e.dtype = dtype; e.B = batch; e.n = n; e.C = C; e.x = x; e.cstats = col_stats; e.groups = groups; e.gn_gamma = gn_gamma;
+  e.gn_beta = gn_beta; e.gn_eps = gn_eps; e.w_in = w_in; e.b_in = b_in; e.ln_gamma = ln_gamma; e.ln_beta = ln_beta; e.ln_eps = ln_eps;
+  e.w_qkv = w_qkv; e.t = t; e.qkv = qkv;
+  T2P_REQUIRE(st_entry_eligible(e), "st_entry: C = 256, 16-bit dtype, n % 32 == 0 (64 with column sums), batch n <= 16384");
+  return launch_st_entry(e, (hipStream_t)stream);
+  API_END
+}
+
 int t2p_op_input_conv(const float* x, const float* w_tcn, const float* bias, void* out, int out_dtype, int batch, int C, int H, int W,
                       int nf, float* col_stats, void* stream) {
   API_BEGIN
@@ -514,6 +527,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 29) { t2p::g_attn_strip = value != 0; return T2P_OK; }
   if (key == 36) { t2p::g_small_conv = value != 0; return T2P_OK; }
   if (key == 38) { t2p::g_pre_conv_split = value != 0; return T2P_OK; }
+  if (key == 39) { t2p::g_st_fuse = value != 0; return T2P_OK; }
   if (key == 34) { set_gemm_a_norm(value != 0); return T2P_OK; }
   if (key == 32) { g_attn_merged = value != 0; return T2P_OK; }
   if (key == 33) { g_ffpo_merged = value != 0; return T2P_OK; }

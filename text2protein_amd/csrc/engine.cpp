@@ -1105,20 +1105,47 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   const long rows = (long)B * n, npad = (long)round_up((size_t)n, 8);
   const float scale = 1.f / std::sqrt((float)d);
   T2P_REQUIRE(L.ctx_k && L.ctx_vt && ctx_B_ == B, "set_context must be called with the same batch before score");
-  void* a = nullptr;
-  T2P_TRY(group_norm(x, nullptr, L.gn0, 1e-6f, 0, 0, B, &a, s));
   // the block's own residual stream t: fp32, or the compute dtype together with the stream between blocks
   const bool tl = res_lowp();
   POOL_GET(t, float*, (size_t)rows * C * (tl ? es : 4));
-  T2P_TRY(linear(a, false, L.proj_in, rows, t, !tl, nullptr, 1.f, s));
-  pool_.put(a);
+  const bool qkv_flash = g_qkv_fused && L.a1_qkv.w && g_flash_attention && attention_flash_eligible(dt, d, 3 * C, 3 * C, 3 * C, C);
+  // GroupNorm -> proj_in -> LayerNorm_1 -> q | k | v as ONE launch where the row-block kernel applies (stfuse.hip)
+  char* qkv_pre = nullptr;
+  if (tl && x.lowp && qkv_flash) {
+    StEntryArgs e;
+    e.dtype = dt; e.B = B; e.n = n; e.C = C;
+    const bool normed = x.pre_norm && x.pre_for == &L.gn0 && x.pre_silu == 0;
+    e.x = normed ? x.pre_norm : (const void*)x.p;
+    e.cstats = normed ? nullptr : x.cstats;
+    e.gn_gamma = L.gn0.gamma; e.gn_beta = L.gn0.beta; e.groups = L.gn0.G; e.gn_eps = 1e-6f;
+    e.w_in = L.proj_in.w; e.b_in = L.proj_in.b;
+    e.ln_gamma = L.ln1.gamma; e.ln_beta = L.ln1.beta; e.ln_eps = 1e-5f;
+    e.w_qkv = L.a1_qkv.w;
+    if ((normed || x.cstats) && L.proj_in.b && st_entry_eligible(e)) {
+      qkv_pre = (char*)pool_.get((size_t)rows * 3 * C * es);
+      if (!qkv_pre) return T2P_ERR_HIP;
+      e.t = t; e.qkv = qkv_pre;
+      T2P_TRY(launch_st_entry(e, s));
+      if (normed) { pool_.put(x.pre_norm); x.pre_norm = nullptr; }
+    }
+  }
+  if (!qkv_pre) {
+    void* a = nullptr;
+    T2P_TRY(group_norm(x, nullptr, L.gn0, 1e-6f, 0, 0, B, &a, s));
+    T2P_TRY(linear(a, false, L.proj_in, rows, t, !tl, nullptr, 1.f, s));
+    pool_.put(a);
+  }
   POOL_GET(ln, void*, (size_t)rows * C * es);
   POOL_GET(o, void*, (size_t)rows * C * es);
   // attn1: self-attention
-  T2P_TRY(launch_layernorm(t, L.ln1.gamma, L.ln1.beta, ln, dt, rows, C, 1e-5f, s, tl));
-  if (g_qkv_fused && L.a1_qkv.w && g_flash_attention && attention_flash_eligible(dt, d, 3 * C, 3 * C, 3 * C, C)) {
-    POOL_GET(qkv, char*, (size_t)rows * 3 * C * es);
-    T2P_TRY(linear(ln, false, L.a1_qkv, rows, qkv, false, nullptr, 1.f, s, false));
+  if (!qkv_pre) T2P_TRY(launch_layernorm(t, L.ln1.gamma, L.ln1.beta, ln, dt, rows, C, 1e-5f, s, tl));
+  if (qkv_flash) {
+    char* qkv = qkv_pre;
+    if (!qkv) {
+      qkv = (char*)pool_.get((size_t)rows * 3 * C * es);
+      if (!qkv) return T2P_ERR_HIP;
+      T2P_TRY(linear(ln, false, L.a1_qkv, rows, qkv, false, nullptr, 1.f, s, false));
+    }
     T2P_TRY(launch_attention_flash(dt, qkv, 3 * C, qkv + (size_t)C * es, 3 * C, qkv + (size_t)2 * C * es, 3 * C, o, B, heads, n, n, d, scale, s,
                                    true));
     pool_.put(qkv);

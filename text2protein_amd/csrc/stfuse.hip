@@ -1,0 +1,309 @@
+// Row-block chains of a SpatialTransformer block in ONE launch each (gfx950).
+//
+// At the 16x16 level of the C = 256 configurations a BasicTransformerBlock (reference model/attention.py:208-215, inside
+// SpatialTransformer.forward :250-263) is 13 launches of ~12 us each for 8192 rows: every one of them is bound by the latency
+// of a dependent launch, not by its arithmetic.  Between the two attention products the block is ROW-WISE: GroupNorm apply,
+// proj_in, LayerNorm, the q | k | v projection (and later out-projection + residual, LayerNorm, the next projection) touch one
+// token at a time.  Such a chain runs here as one kernel:
+//   * a workgroup (8 wavefronts) owns 32 rows (two MFMA row tiles) of one sample and keeps them in LDS (padded rows: conflict-free
+//     16-byte fragment reads) from stage to stage;
+//   * a stage's weights [N][K] stream from global memory (L2) straight into MFMA fragments, column tile by column tile, one tile
+//     ahead; wavefront w computes column tiles w, w + 8, ... for both row tiles from A fragments it loads once per stage;
+//     v_mfma_f32_16x16x32 with the weights first, so a lane ends with 4 consecutive channels of one row;
+//   * nothing is exchanged between workgroups; every workgroup re-reads the stage weights (256 x 0.5 MB at C = 256: L2 traffic
+//     of a few microseconds), which is what limits the idea to C = 256 and to levels of <= 8192 rows.
+// st_entry_kernel: a = GroupNorm(x) (statistics from the producer's per-64-row column sums, folded in double, or x already
+// normalised) -> t = proj_in(a) + b -> LayerNorm_1(t) -> q | k | v: the first four launches of the block.
+#include <algorithm>
+
+#include "t2p_kernels.h"
+
+namespace t2p {
+
+typedef unsigned sf_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned sf_u32x2 __attribute__((ext_vector_type(2)));
+typedef float sf_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 sf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sf_f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename TC> struct SfMma;
+template <> struct SfMma<bf16_t> {
+  __device__ static inline void run(const sf_u32x4& a, const sf_u32x4& b, sf_f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sf_bf16x8, a), __builtin_bit_cast(sf_bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct SfMma<f16_t> {
+  __device__ static inline void run(const sf_u32x4& a, const sf_u32x4& b, sf_f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sf_f16x8, a), __builtin_bit_cast(sf_f16x8, b), c, 0, 0, 0);
+  }
+};
+template <typename TC> __device__ inline unsigned sf_pack2(float a, float b);
+template <> __device__ inline unsigned sf_pack2<bf16_t>(float a, float b) {
+  return (unsigned)f32_to_bf16_bits(a) | ((unsigned)f32_to_bf16_bits(b) << 16);
+}
+template <> __device__ inline unsigned sf_pack2<f16_t>(float a, float b) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  h2 v = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+template <typename TC> __device__ inline float sf_lo(unsigned u) { return to_f32(__builtin_bit_cast(TC, (uint16_t)(u & 0xffffu))); }
+template <typename TC> __device__ inline float sf_hi(unsigned u) { return to_f32(__builtin_bit_cast(TC, (uint16_t)(u >> 16))); }
+
+// sum over the 64 lanes of a wavefront, every lane ends with the total (fixed order)
+__device__ inline float sf_wave_sum(float x) {
+#pragma unroll
+  for (int sh = 1; sh < 64; sh <<= 1) x += __shfl_xor(x, sh, 64);
+  return x;
+}
+
+constexpr int SF_ROWS = 32;
+#ifdef SF_TIMING     // measurement variant (tools/build_variant.py): phase stamps of workgroup 0 (100 MHz clock) over the first bytes of qkv
+#define SF_STAMP(i) if (blockIdx.x == 0 && threadIdx.x == 0) sf_stamps[i] = __builtin_amdgcn_s_memrealtime();
+#define SF_STAMPS_OUT(p) if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) ((unsigned long long*)(p))[i_] = sf_stamps[i_]; }
+#else
+#define SF_STAMP(i)
+#define SF_STAMPS_OUT(p)
+#endif
+
+// One stage: out[32][N] = A[32][K] W[N][K]^T with A in LDS (row stride RS bytes), N = 128 TPW.  Wavefront `wave` of 8 takes the TPW
+// column tiles wave, wave + 8, ...; `epi(i, ct, acc)` receives the two row tiles of a finished column tile: acc[rt][e] = row
+// 16 rt + (lane & 15), column 16 ct + 4 (lane >> 4) + e.  The weight fragments of a column tile are one L2 round trip away and
+// its matrix work is 16 MFMAs: DEPTH tiles are kept in flight (`ring`, filled by sf_prefetch ahead of the stage: a one-tile
+// look-ahead left the q | k | v stage waiting for every tile: 25.6 us for the whole chain).
+template <typename TC, int K, int RS, int TPW, int DEPTH, typename Epi>
+__device__ __forceinline__ void sf_stage(const unsigned char* a_lds, const TC* W, const int wave, const int lane,
+                                         sf_u32x4 (&ring)[DEPTH][K / 32], Epi&& epi) {
+  constexpr int NS = K / 32;
+  const int l16 = lane & 15, g4 = lane >> 4;
+  sf_u32x4 af[2][NS];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) af[rt][s] = *(const sf_u32x4*)(a_lds + (rt * 16 + l16) * RS + (32 * s + 8 * g4) * 2);
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int ct = wave + 8 * i;
+    sf_f32x4 acc[2] = {sf_f32x4{0.f, 0.f, 0.f, 0.f}, sf_f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      SfMma<TC>::run(ring[i % DEPTH][s], af[0][s], acc[0]);
+      SfMma<TC>::run(ring[i % DEPTH][s], af[1][s], acc[1]);
+    }
+    if (i + DEPTH < TPW) {                                  // this slot's fragments are consumed: request the tile DEPTH ahead
+      const TC* wr = W + (long)((ct + 8 * DEPTH) * 16 + l16) * K + 8 * g4;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) ring[i % DEPTH][s] = *(const sf_u32x4*)(wr + 32 * s);
+    }
+    epi(i, ct, acc);
+  }
+}
+// the fragments of this wavefront's first min(DEPTH, TPW) column tiles of W [N][K] (what sf_stage expects in `ring`)
+template <typename TC, int K, int TPW, int DEPTH>
+__device__ __forceinline__ void sf_prefetch(const TC* W, const int wave, const int lane, sf_u32x4 (&ring)[DEPTH][K / 32]) {
+  const int l16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i) {
+    if (i < TPW) {
+      const TC* wr = W + (long)((wave + 8 * i) * 16 + l16) * K + 8 * g4;
+#pragma unroll
+      for (int s = 0; s < K / 32; ++s) ring[i][s] = *(const sf_u32x4*)(wr + 32 * s);
+    }
+  }
+}
+
+// LayerNorm of the 32 rows of `buf` in place: wavefront w takes rows 4 w .. 4 w + 3, a lane C / 64 consecutive channels
+template <typename TC, int C, int RS>
+__device__ __forceinline__ void sf_layernorm(unsigned char* buf, const float (&ga)[C / 64], const float (&be)[C / 64], const float eps,
+                                             const int wave, const int lane) {
+  constexpr int PER = C / 64;                                // 4 (C = 256) or 8 (C = 512) channels per lane; ga / be: its gamma / beta
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    unsigned char* row = buf + (wave * 4 + r) * RS + lane * PER * 2;
+    float v[PER];
+    if constexpr (PER == 4) {
+      const sf_u32x2 u = *(const sf_u32x2*)row;
+      v[0] = sf_lo<TC>(u[0]); v[1] = sf_hi<TC>(u[0]); v[2] = sf_lo<TC>(u[1]); v[3] = sf_hi<TC>(u[1]);
+    } else {
+      const sf_u32x4 u = *(const sf_u32x4*)row;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[2 * k] = sf_lo<TC>(u[k]); v[2 * k + 1] = sf_hi<TC>(u[k]); }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) s += v[k];
+    const float mean = sf_wave_sum(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const float d = v[k] - mean; q += d * d; }
+    const float rstd = 1.f / sqrtf(sf_wave_sum(q) * (1.f / C) + eps);
+    float y[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) y[k] = (v[k] - mean) * rstd * ga[k] + be[k];
+    if constexpr (PER == 4) {
+      *(sf_u32x2*)row = sf_u32x2{sf_pack2<TC>(y[0], y[1]), sf_pack2<TC>(y[2], y[3])};
+    } else {
+      *(sf_u32x4*)row = sf_u32x4{sf_pack2<TC>(y[0], y[1]), sf_pack2<TC>(y[2], y[3]), sf_pack2<TC>(y[4], y[5]), sf_pack2<TC>(y[6], y[7])};
+    }
+  }
+}
+
+template <typename TC, int C>
+__global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
+  constexpr int RS = C * 2 + 16;                             // LDS row stride: an odd number of 16-byte units
+  constexpr int NS = C / 32;
+  __shared__ __attribute__((aligned(16))) unsigned char bufx[SF_ROWS * RS];
+  __shared__ __attribute__((aligned(16))) unsigned char buft[SF_ROWS * RS];
+  __shared__ double dred[2][C];
+  __shared__ float gsc[C], gsh[C];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, g4 = lane >> 4;
+  const int m0 = blockIdx.x * SF_ROWS;
+  const int b = m0 / a.n;                                    // n % 32 == 0: the rows of a workgroup lie in one sample
+  const TC* Win = (const TC*)a.w_in;
+  const TC* Wqkv = (const TC*)a.w_qkv;
+#ifdef SF_TIMING
+  unsigned long long sf_stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  SF_STAMP(0)
+
+  // independent of everything: this wavefront's proj_in fragments (both of its column tiles) and the rows themselves
+  constexpr int DEPTH = 3;
+  sf_u32x4 ring[DEPTH][NS];
+  sf_prefetch<TC, C, C / 128, DEPTH>(Win, wave, lane, ring);
+  constexpr int XPT = SF_ROWS * (C / 8) / 512;               // 16-byte pieces of the row block per thread
+  sf_u32x4 xr[XPT];
+  {
+    const TC* X = (const TC*)a.x + (long)m0 * C;
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) {
+      const int i = tid + 512 * k, r = i / (C / 8), j = i - r * (C / 8);
+      xr[k] = *(const sf_u32x4*)(X + (long)r * C + j * 8);
+    }
+  }
+
+  // ... and every other operand that depends on nothing: a workgroup is a chain of dependent round trips (the first version loaded
+  // the column sums chunk by chunk and gamma / beta / biases where they were used: 8 serial trips, 25.6 us per launch)
+  constexpr int PER = C / 64;
+  float lga[PER], lbe[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { lga[k] = a.ln_gamma[lane * PER + k]; lbe[k] = a.ln_beta[lane * PER + k]; }
+  float4 bin[C / 128];
+#pragma unroll
+  for (int i = 0; i < C / 128; ++i) bin[i] = *(const float4*)(a.b_in + (wave + 8 * i) * 16 + 4 * g4);
+  // ---- GroupNorm scale / shift of this sample (gn_apply_cols_kernel's arithmetic: column sums folded in double) ----------------
+  if (a.cstats) {
+    const int nchunk = a.n >> 6, cpg = C / a.groups;
+    const int c = tid & (C - 1), part = tid / C;             // 512 / C threads per channel, each every (512 / C)-th chunk, 4 loads in flight
+    constexpr int PARTS = 512 / C;
+    const float ggam = a.gn_gamma[c], gbet = a.gn_beta[c];
+    double s = 0, q = 0;
+    const float* cs = a.cstats + ((long)b * nchunk * C + c) * 2;
+    int ch = part;
+    for (; ch + 3 * PARTS < nchunk; ch += 4 * PARTS) {
+      const float2 v0 = *(const float2*)(cs + (long)ch * C * 2), v1 = *(const float2*)(cs + (long)(ch + PARTS) * C * 2);
+      const float2 v2 = *(const float2*)(cs + (long)(ch + 2 * PARTS) * C * 2), v3 = *(const float2*)(cs + (long)(ch + 3 * PARTS) * C * 2);
+      s += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+      q += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; ch < nchunk; ch += PARTS) {
+      const float2 v = *(const float2*)(cs + (long)ch * C * 2);
+      s += v.x; q += v.y;
+    }
+    if (part > 0) { dred[0][c] = s; dred[1][c] = q; }       // (C = 256: two parts; the first adds the second's sums)
+    __syncthreads();
+    if (part == 0) {
+      if (PARTS > 1) { s += dred[0][c]; q += dred[1][c]; }
+    }
+    __syncthreads();
+    if (part == 0) { dred[0][c] = s; dred[1][c] = q; }
+    __syncthreads();
+    if (part == 0) {
+      const int g0 = (c / cpg) * cpg;
+      double gs = 0, gq = 0;
+      for (int k = 0; k < cpg; ++k) { gs += dred[0][g0 + k]; gq += dred[1][g0 + k]; }
+      const double cnt = (double)a.n * cpg, mean = gs / cnt;
+      double var = gq / cnt - mean * mean;
+      if (var < 0) var = 0;
+      const float rstd = (float)(1.0 / sqrt(var + (double)a.gn_eps));
+      const float sc = rstd * ggam;
+      gsc[c] = sc;
+      gsh[c] = gbet - (float)mean * sc;
+    }
+    __syncthreads();
+  }
+  SF_STAMP(1)
+  // ---- rows -> LDS (normalised on the way unless the producer already did) ---------------------------------------------------------
+#pragma unroll
+  for (int k = 0; k < XPT; ++k) {
+    const int i = tid + 512 * k, r = i / (C / 8), j = i - r * (C / 8);
+    sf_u32x4 u = xr[k];
+    if (a.cstats) {
+      unsigned o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = j * 8 + 2 * q;
+        o[q] = sf_pack2<TC>(sf_lo<TC>(u[q]) * gsc[c] + gsh[c], sf_hi<TC>(u[q]) * gsc[c + 1] + gsh[c + 1]);
+      }
+      u = sf_u32x4{o[0], o[1], o[2], o[3]};
+    }
+    *(sf_u32x4*)(bufx + r * RS + j * 16) = u;
+  }
+  __syncthreads();
+  SF_STAMP(2)
+  // ---- t = proj_in(a) + bias: to global memory (the block's residual stream) and to LDS -----------------------------------------
+  {
+    TC* T = (TC*)a.t;
+    sf_stage<TC, C, RS, C / 128, DEPTH>(bufx, Win, wave, lane, ring, [&](int i, int ct, sf_f32x4 (&acc)[2]) {
+      const int col = ct * 16 + 4 * g4;
+      const float4 bb = bin[i];                              // (i: compile-time after unrolling)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int r = rt * 16 + l16;
+        const sf_u32x2 o = {sf_pack2<TC>(acc[rt][0] + bb.x, acc[rt][1] + bb.y), sf_pack2<TC>(acc[rt][2] + bb.z, acc[rt][3] + bb.w)};
+        *(sf_u32x2*)(buft + r * RS + col * 2) = o;
+        *(sf_u32x2*)(T + (long)(m0 + r) * C + col) = o;
+      }
+    });
+  }
+  SF_STAMP(3)
+  sf_prefetch<TC, C, 3 * C / 128, DEPTH>(Wqkv, wave, lane, ring);      // the next stage's first fragments travel during the LayerNorm
+  __syncthreads();
+  SF_STAMP(4)
+  sf_layernorm<TC, C, RS>(buft, lga, lbe, a.ln_eps, wave, lane);
+  __syncthreads();
+  SF_STAMP(5)
+  // ---- q | k | v = LayerNorm_1(t) W_qkv^T (CrossAttention.to_q / to_k / to_v carry no bias) -------------------------------------
+  {
+    TC* Q = (TC*)a.qkv;
+    sf_stage<TC, C, RS, 3 * C / 128, DEPTH>(buft, Wqkv, wave, lane, ring, [&](int i, int ct, sf_f32x4 (&acc)[2]) {
+      const int col = ct * 16 + 4 * g4;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int r = rt * 16 + l16;
+        *(sf_u32x2*)(Q + (long)(m0 + r) * (3 * C) + col) =
+            sf_u32x2{sf_pack2<TC>(acc[rt][0], acc[rt][1]), sf_pack2<TC>(acc[rt][2], acc[rt][3])};
+      }
+    });
+  }
+  SF_STAMP(6)
+  SF_STAMPS_OUT(a.qkv)
+}
+
+bool g_st_fuse = true;      // plan switch 39
+bool st_entry_eligible(const StEntryArgs& a) {
+  if (!g_st_fuse || (a.dtype != DT_F16 && a.dtype != DT_BF16) || a.C != 256) return false;
+  if (a.n % SF_ROWS != 0 || (long)a.B * a.n > 16384) return false;
+  if (a.cstats && (a.n % 64 != 0 || a.groups <= 0 || a.C % a.groups != 0)) return false;
+  return true;
+}
+int launch_st_entry(const StEntryArgs& a, hipStream_t s) {
+  T2P_REQUIRE(st_entry_eligible(a) && a.x && a.w_in && a.b_in && a.ln_gamma && a.ln_beta && a.w_qkv && a.t && a.qkv, "st_entry arguments");
+  T2P_REQUIRE(!a.cstats || (a.gn_gamma && a.gn_beta), "st_entry: GroupNorm parameters");
+  const dim3 grid((unsigned)((long)a.B * a.n / SF_ROWS));
+  if (a.dtype == DT_F16) hipLaunchKernelGGL((st_entry_kernel<f16_t, 256>), grid, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((st_entry_kernel<bf16_t, 256>), grid, dim3(512), 0, s, a);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+}  // namespace t2p

@@ -170,6 +170,24 @@ struct SmallConvArgs {
   float gn_eps = 1e-6f;
 };
 extern bool g_small_conv;
+
+// ---- row-block chains of a SpatialTransformer block in one launch (stfuse.hip; plan switch 39) -------------------------------------
+// st_entry: a = GroupNorm(x) -> t = proj_in(a) + b -> LayerNorm_1(t) -> q | k | v  (model/attention.py:250-256, 208-213, 170-176)
+struct StEntryArgs {
+  int dtype = DT_F16;
+  int B = 0, n = 0, C = 0;               // samples, tokens per sample (H W), channels
+  const void* x = nullptr;               // [B n][C] 16-bit: the block input (raw with cstats, already normalised without)
+  const float* cstats = nullptr;         // per-64-row column sums of x ([B n / 64][C][2]) or null
+  const float* gn_gamma = nullptr; const float* gn_beta = nullptr; int groups = 0; float gn_eps = 1e-6f;
+  const void* w_in = nullptr; const float* b_in = nullptr;       // proj_in [C][C] 16-bit, bias [C]
+  const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 1e-5f;
+  const void* w_qkv = nullptr;           // [3 C][C] 16-bit: to_q | to_k | to_v stacked (no bias)
+  void* t = nullptr;                     // out [B n][C] 16-bit: the block's residual stream
+  void* qkv = nullptr;                   // out [B n][3 C] 16-bit
+};
+extern bool g_st_fuse;
+bool st_entry_eligible(const StEntryArgs& a);
+int launch_st_entry(const StEntryArgs& a, hipStream_t s);
 bool small_conv_eligible(const SmallConvArgs& a);
 int launch_small_conv_gn(const SmallConvArgs& a, hipStream_t s);
 
