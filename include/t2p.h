@@ -186,14 +186,18 @@ int t2p_op_small_conv_groupnorm(int dtype, const void* a, const void* w, int64_t
                                 const float* bias, const float* bias_bn, const void* residual, float alpha, void* out, int out_f32,
                                 float* col_stats, void* normed, int groups, const float* gamma, const float* beta, float eps, int silu,
                                 int batch, int H, int W, int C, int Cout, void* stream);
-/* the first four launches of a SpatialTransformer block (model/attention.py:250-256 GroupNorm + proj_in, :208-213 LayerNorm_1,
- * :170-176 to_q / to_k / to_v) as ONE launch over 32-row blocks: a = GroupNorm(x) (statistics from col_stats, the per-64-row
- * column sums of x, [batch n / 64][C][2]; col_stats == NULL: x is already normalised), t = a W_in^T + b_in (the block's residual
- * stream, 16-bit), qkv = LayerNorm(t) W_qkv^T (16-bit, [batch n][3 C]).  x, w_in [C][C], w_qkv [3 C][C] in the 16-bit compute
- * dtype.  C = 256, n % 32 == 0 (n % 64 == 0 with col_stats), batch n <= 16384; anything else is refused */
+/* row-wise chains of a SpatialTransformer block as ONE launch over 32-row blocks (model/attention.py:250-256 GroupNorm + proj_in,
+ * :208-215 LayerNorm + residual adds, :170-193 to_q / to_k / to_v / to_out):
+ *   t = a W_in^T + b_in (+ residual);  out2 = LayerNorm(t) W_2^T        (t [batch n][C], out2 [batch n][n2], 16-bit)
+ * with a = GroupNorm(x) (statistics from col_stats, the per-64-row column sums of x, [batch n / 64][C][2]) or a = x (col_stats
+ * NULL).  Entry of the block: W_in = proj_in, W_2 = to_q | to_k | to_v stacked (n2 = 3 C).  After the self-attention: x = its
+ * output, W_in = to_out, residual = t (may alias the output t), W_2 = the cross-attention's to_q (n2 = C).
+ * x, w_in [C][C], w_2 [n2][C], residual in the 16-bit compute dtype.  C = 256, n % 32 == 0 (n % 64 == 0 with col_stats),
+ * batch n <= 16384; anything else is refused */
 int t2p_op_st_entry(int dtype, const void* x, const float* col_stats, int groups, const float* gn_gamma, const float* gn_beta,
-                    float gn_eps, const void* w_in, const float* b_in, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                    const void* w_qkv, void* t, void* qkv, int batch, int n, int C, void* stream);
+                    float gn_eps, const void* w_in, const float* b_in, const void* residual, const float* ln_gamma,
+                    const float* ln_beta, float ln_eps, const void* w_2, int n2, void* t, void* out2, int batch, int n, int C,
+                    void* stream);
 /* the network's input convolution (pre_conv, ncsnpp.py:230: 3x3, C = 5 or 8 input channels -> nf) straight from the NCHW fp32
  * sample, in fp32 arithmetic: x [batch][C][H][W] fp32; w_tcn [3*3][C][nf] fp32 (tap-major); out NHWC [batch][H][W][nf] in
  * out_dtype.  col_stats (optional; W % 64 == 0, nf | 256): [batch H W / 64][nf][2] fp32 = (sum, sum of squares) of the fp32

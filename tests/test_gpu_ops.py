@@ -531,50 +531,54 @@ def test_input_conv_and_its_column_statistics(lib, C, nf, H, W):
 
 
 @pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("B,n,with_stats", [(3, 256, True), (2, 64, True), (5, 32, False), (32, 256, True), (1, 1024, False)])
-def test_spatial_transformer_entry_chain(lib, dt, B, n, with_stats):
-    """t2p_op_st_entry: GroupNorm -> proj_in -> LayerNorm_1 -> q | k | v of a SpatialTransformer block (model/attention.py:250-256,
-    208-213, 170-176) in one launch over 32-row blocks, against the same chain in fp64 with the intermediate roundings of the
-    separate launches (a, t, LayerNorm(t) stored in the compute dtype).  With the producer's column sums (GroupNorm inside) and
-    with an already normalised input."""
+@pytest.mark.parametrize("B,n,mode", [(3, 256, "entry"), (2, 64, "entry"), (5, 32, "normed"), (32, 256, "entry"), (1, 1024, "normed"),
+                                      (3, 256, "mid"), (32, 256, "mid"), (4, 64, "mid")])
+def test_spatial_transformer_row_chain(lib, dt, B, n, mode):
+    """t2p_op_st_entry: the row-wise chains of a SpatialTransformer block in one launch over 32-row blocks, against the same chain
+    in fp64 with the intermediate roundings of the separate launches (a, t, LayerNorm(t) stored in the compute dtype).
+    entry: GroupNorm (from the producer's column sums) -> proj_in -> LayerNorm_1 -> q | k | v (model/attention.py:250-256, 208-213);
+    normed: the same with an already normalised input; mid: t += to_out(o) + b -> LayerNorm_2 -> to_q, in place (:211-213, 186-193)."""
     C, G = 256, 32
     td = TDT[dt]
-    g = torch.Generator().manual_seed(17 * n + B)
+    g = torch.Generator().manual_seed(17 * n + B + len(mode))
     x = (torch.randn(B, n, C, generator=g) * 1.5 + 0.3 * torch.randn(B, 1, C, generator=g)).to(td)
     gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
     w_in = (torch.randn(C, C, generator=g) / C ** 0.5).to(td)
     b_in = 0.3 * torch.randn(C, generator=g)
     lg, lb = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
-    w_qkv = (torch.randn(3 * C, C, generator=g) / C ** 0.5).to(td)
+    n2 = C if mode == "mid" else 3 * C
+    w_2 = (torch.randn(n2, C, generator=g) / C ** 0.5).to(td)
+    res = (torch.randn(B, n, C, generator=g) * 2).to(td) if mode == "mid" else None
     xd = x.double()
-    if with_stats:
+    csp = None
+    if mode == "entry":
         xg = xd.reshape(B, n, G, C // G)
         mean = xg.mean(dim=(1, 3), keepdim=True)
         var = xg.var(dim=(1, 3), unbiased=False, keepdim=True)
         a = (((xg - mean) / torch.sqrt(var + 1e-6)).reshape(B, n, C) * gamma.double() + beta.double()).to(td)
         chunks = x.float().reshape(B * n // 64, 64, C)
         cs = torch.stack([chunks.sum(1), (chunks ** 2).sum(1)], dim=-1).contiguous()          # [B n / 64][C][2]
-        src, csp = x, P(dev(cs))
+        csp = P(dev(cs))
     else:
         a = x
-        src, csp = x, None
-    t_ref = (a.double() @ w_in.double().T + b_in.double()).to(td)
+    t_ref = (a.double() @ w_in.double().T + b_in.double() + (res.double() if res is not None else 0.0)).to(td)
     td_ = t_ref.double()
     ln = ((td_ - td_.mean(-1, keepdim=True)) / torch.sqrt(td_.var(-1, unbiased=False, keepdim=True) + 1e-5) * lg.double() + lb.double()).to(td)
-    qkv_ref = ln.double() @ w_qkv.double().T
-    t = torch.full((B, n, C), float("nan"), device="cuda", dtype=td)
-    qkv = torch.full((B, n, 3 * C), float("nan"), device="cuda", dtype=td)
-    check(lib, lib.t2p_op_st_entry(dt, P(dev(src)), csp, G, P(dev(gamma)), P(dev(beta)), 1e-6, P(dev(w_in)), P(dev(b_in)), P(dev(lg)),
-                                   P(dev(lb)), 1e-5, P(dev(w_qkv)), P(t), P(qkv), B, n, C, None))
+    out2_ref = ln.double() @ w_2.double().T
+    # mid: the residual stream is updated in place
+    t = dev(res).clone() if res is not None else torch.full((B, n, C), float("nan"), device="cuda", dtype=td)
+    out2 = torch.full((B, n, n2), float("nan"), device="cuda", dtype=td)
+    args = lambda CC, nn: (dt, P(dev(x)), csp, G, P(dev(gamma)), P(dev(beta)), 1e-6, P(dev(w_in)), P(dev(b_in)), P(t) if res is not None else None,
+                           P(dev(lg)), P(dev(lb)), 1e-5, P(dev(w_2)), n2, P(t), P(out2), B, nn, CC, None)
+    check(lib, lib.t2p_op_st_entry(*args(C, n)))
     torch.cuda.synchronize()
     tol = 1.5e-3 if dt == 2 else 1.2e-2
     assert rel_l2(t.float().cpu(), t_ref.double()) < tol
-    assert rel_l2(qkv.float().cpu(), qkv_ref) < 2 * tol
+    assert rel_l2(out2.float().cpu(), out2_ref) < 2 * tol
     # refused, not silently computed by something else: other channel counts, ragged row blocks
-    assert lib.t2p_op_st_entry(dt, P(dev(src)), None, G, None, None, 1e-6, P(dev(w_in)), P(dev(b_in)), P(dev(lg)), P(dev(lb)), 1e-5,
-                               P(dev(w_qkv)), P(t), P(qkv), B, n, 128, None) != 0
-    assert lib.t2p_op_st_entry(dt, P(dev(src)), None, G, None, None, 1e-6, P(dev(w_in)), P(dev(b_in)), P(dev(lg)), P(dev(lb)), 1e-5,
-                               P(dev(w_qkv)), P(t), P(qkv), B, 48, C, None) != 0
+    if csp is None:
+        assert lib.t2p_op_st_entry(*args(128, n)) != 0
+        assert lib.t2p_op_st_entry(*args(C, 48)) != 0
 
 
 def test_input_conv_split_operands_keep_fp32_accuracy(lib):

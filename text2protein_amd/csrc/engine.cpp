@@ -1120,7 +1120,7 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     e.gn_gamma = L.gn0.gamma; e.gn_beta = L.gn0.beta; e.groups = L.gn0.G; e.gn_eps = 1e-6f;
     e.w_in = L.proj_in.w; e.b_in = L.proj_in.b;
     e.ln_gamma = L.ln1.gamma; e.ln_beta = L.ln1.beta; e.ln_eps = 1e-5f;
-    e.w_qkv = L.a1_qkv.w;
+    e.w_qkv = L.a1_qkv.w; e.n2 = 3 * C;
     if ((normed || x.cstats) && L.proj_in.b && st_entry_eligible(e)) {
       qkv_pre = (char*)pool_.get((size_t)rows * 3 * C * es);
       if (!qkv_pre) return T2P_ERR_HIP;
@@ -1158,12 +1158,20 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     pool_.put(qk);
     pool_.put(vt);
   }
-  T2P_TRY(linear(o, false, L.a1_out, rows, t, !tl, t, 1.f, s, true, nullptr, tl));
-  // attn2: cross-attention to the cached text keys / values
-  T2P_TRY(launch_layernorm(t, L.ln2.gamma, L.ln2.beta, ln, dt, rows, C, 1e-5f, s, tl));
+  // attn2: cross-attention to the cached text keys / values.  t += to_out(o) -> LayerNorm_2 -> to_q: one launch where the row-block
+  // kernel applies (the first product's residual and output are both t: a workgroup's rows are its own)
   {
     POOL_GET(q, void*, (size_t)rows * C * es);
-    T2P_TRY(linear(ln, false, L.a2_q, rows, q, false, nullptr, 1.f, s, false));
+    StEntryArgs e;
+    e.dtype = dt; e.B = B; e.n = n; e.C = C; e.x = o; e.w_in = L.a1_out.w; e.b_in = L.a1_out.b; e.res = t;
+    e.ln_gamma = L.ln2.gamma; e.ln_beta = L.ln2.beta; e.ln_eps = 1e-5f; e.w_qkv = L.a2_q.w; e.n2 = C; e.t = t; e.qkv = q;
+    if (tl && qkv_pre && L.a1_out.b && !L.a2_q.b && st_entry_eligible(e)) {
+      T2P_TRY(launch_st_entry(e, s));
+    } else {
+      T2P_TRY(linear(o, false, L.a1_out, rows, t, !tl, t, 1.f, s, true, nullptr, tl));
+      T2P_TRY(launch_layernorm(t, L.ln2.gamma, L.ln2.beta, ln, dt, rows, C, 1e-5f, s, tl));
+      T2P_TRY(linear(ln, false, L.a2_q, rows, q, false, nullptr, 1.f, s, false));
+    }
     T2P_TRY(attention(q, C, L.ctx_k, C, L.ctx_vt, ctx_Tpad_, o, B, heads, n, ctx_T_, d, scale, s));
     pool_.put(q);
   }

@@ -13,7 +13,8 @@
 //   * nothing is exchanged between workgroups; every workgroup re-reads the stage weights (256 x 0.5 MB at C = 256: L2 traffic
 //     of a few microseconds), which is what limits the idea to C = 256 and to levels of <= 8192 rows.
 // st_entry_kernel: a = GroupNorm(x) (statistics from the producer's per-64-row column sums, folded in double, or x already
-// normalised) -> t = proj_in(a) + b -> LayerNorm_1(t) -> q | k | v: the first four launches of the block.
+// normalised) -> t = proj_in(a) + b -> LayerNorm_1(t) -> q | k | v: the first four launches of the block.  The same kernel with a
+// residual and N2 = C is the chain after the self-attention: t += to_out(o) + b -> LayerNorm_2(t) -> to_q of the cross-attention.
 #include <algorithm>
 
 #include "t2p_kernels.h"
@@ -147,7 +148,7 @@ __device__ __forceinline__ void sf_layernorm(unsigned char* buf, const float (&g
   }
 }
 
-template <typename TC, int C>
+template <typename TC, int C, int TPW2>      // TPW2: column tiles of the second product per wavefront (N2 = 128 TPW2: 3 C or C)
 __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
   constexpr int RS = C * 2 + 16;                             // LDS row stride: an odd number of 16-byte units
   constexpr int NS = C / 32;
@@ -190,6 +191,12 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
   float4 bin[C / 128];
 #pragma unroll
   for (int i = 0; i < C / 128; ++i) bin[i] = *(const float4*)(a.b_in + (wave + 8 * i) * 16 + 4 * g4);
+  sf_u32x2 rres[C / 128][2];                                 // residual of the first product: this lane's 4 channels of its two rows per tile
+#pragma unroll
+  for (int i = 0; i < C / 128; ++i)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+      rres[i][rt] = a.res ? *(const sf_u32x2*)((const TC*)a.res + (long)(m0 + rt * 16 + l16) * C + (wave + 8 * i) * 16 + 4 * g4) : sf_u32x2{0u, 0u};
   // ---- GroupNorm scale / shift of this sample (gn_apply_cols_kernel's arithmetic: column sums folded in double) ----------------
   if (a.cstats) {
     const int nchunk = a.n >> 6, cpg = C / a.groups;
@@ -259,14 +266,16 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const int r = rt * 16 + l16;
-        const sf_u32x2 o = {sf_pack2<TC>(acc[rt][0] + bb.x, acc[rt][1] + bb.y), sf_pack2<TC>(acc[rt][2] + bb.z, acc[rt][3] + bb.w)};
+        const sf_u32x2 rr = rres[i][rt];                     // (zeros without a residual)
+        const sf_u32x2 o = {sf_pack2<TC>(acc[rt][0] + bb.x + sf_lo<TC>(rr[0]), acc[rt][1] + bb.y + sf_hi<TC>(rr[0])),
+                            sf_pack2<TC>(acc[rt][2] + bb.z + sf_lo<TC>(rr[1]), acc[rt][3] + bb.w + sf_hi<TC>(rr[1]))};
         *(sf_u32x2*)(buft + r * RS + col * 2) = o;
         *(sf_u32x2*)(T + (long)(m0 + r) * C + col) = o;
       }
     });
   }
   SF_STAMP(3)
-  sf_prefetch<TC, C, 3 * C / 128, DEPTH>(Wqkv, wave, lane, ring);      // the next stage's first fragments travel during the LayerNorm
+  sf_prefetch<TC, C, TPW2, DEPTH>(Wqkv, wave, lane, ring);      // the next stage's first fragments travel during the LayerNorm
   __syncthreads();
   SF_STAMP(4)
   sf_layernorm<TC, C, RS>(buft, lga, lbe, a.ln_eps, wave, lane);
@@ -275,12 +284,12 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
   // ---- q | k | v = LayerNorm_1(t) W_qkv^T (CrossAttention.to_q / to_k / to_v carry no bias) -------------------------------------
   {
     TC* Q = (TC*)a.qkv;
-    sf_stage<TC, C, RS, 3 * C / 128, DEPTH>(buft, Wqkv, wave, lane, ring, [&](int i, int ct, sf_f32x4 (&acc)[2]) {
+    sf_stage<TC, C, RS, TPW2, DEPTH>(buft, Wqkv, wave, lane, ring, [&](int i, int ct, sf_f32x4 (&acc)[2]) {
       const int col = ct * 16 + 4 * g4;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const int r = rt * 16 + l16;
-        *(sf_u32x2*)(Q + (long)(m0 + r) * (3 * C) + col) =
+        *(sf_u32x2*)(Q + (long)(m0 + r) * (128 * TPW2) + col) =
             sf_u32x2{sf_pack2<TC>(acc[rt][0], acc[rt][1]), sf_pack2<TC>(acc[rt][2], acc[rt][3])};
       }
     });
@@ -292,7 +301,7 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
 bool g_st_fuse = true;      // plan switch 39
 bool st_entry_eligible(const StEntryArgs& a) {
   if (!g_st_fuse || (a.dtype != DT_F16 && a.dtype != DT_BF16) || a.C != 256) return false;
-  if (a.n % SF_ROWS != 0 || (long)a.B * a.n > 16384) return false;
+  if (a.n % SF_ROWS != 0 || (long)a.B * a.n > 16384 || (a.n2 != a.C && a.n2 != 3 * a.C)) return false;
   if (a.cstats && (a.n % 64 != 0 || a.groups <= 0 || a.C % a.groups != 0)) return false;
   return true;
 }
@@ -300,8 +309,13 @@ int launch_st_entry(const StEntryArgs& a, hipStream_t s) {
   T2P_REQUIRE(st_entry_eligible(a) && a.x && a.w_in && a.b_in && a.ln_gamma && a.ln_beta && a.w_qkv && a.t && a.qkv, "st_entry arguments");
   T2P_REQUIRE(!a.cstats || (a.gn_gamma && a.gn_beta), "st_entry: GroupNorm parameters");
   const dim3 grid((unsigned)((long)a.B * a.n / SF_ROWS));
-  if (a.dtype == DT_F16) hipLaunchKernelGGL((st_entry_kernel<f16_t, 256>), grid, dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((st_entry_kernel<bf16_t, 256>), grid, dim3(512), 0, s, a);
+  if (a.n2 == 3 * a.C) {
+    if (a.dtype == DT_F16) hipLaunchKernelGGL((st_entry_kernel<f16_t, 256, 6>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((st_entry_kernel<bf16_t, 256, 6>), grid, dim3(512), 0, s, a);
+  } else {
+    if (a.dtype == DT_F16) hipLaunchKernelGGL((st_entry_kernel<f16_t, 256, 2>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((st_entry_kernel<bf16_t, 256, 2>), grid, dim3(512), 0, s, a);
+  }
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }

@@ -181,9 +181,11 @@ struct StEntryArgs {
   const float* gn_gamma = nullptr; const float* gn_beta = nullptr; int groups = 0; float gn_eps = 1e-6f;
   const void* w_in = nullptr; const float* b_in = nullptr;       // proj_in [C][C] 16-bit, bias [C]
   const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 1e-5f;
-  const void* w_qkv = nullptr;           // [3 C][C] 16-bit: to_q | to_k | to_v stacked (no bias)
+  const void* res = nullptr;             // optional [B n][C] 16-bit residual of the first product (may be `t` itself: rows are private)
+  const void* w_qkv = nullptr;           // [n2][C] 16-bit: to_q | to_k | to_v stacked (n2 = 3 C), or one projection (n2 = C); no bias
+  int n2 = 0;
   void* t = nullptr;                     // out [B n][C] 16-bit: the block's residual stream
-  void* qkv = nullptr;                   // out [B n][3 C] 16-bit
+  void* qkv = nullptr;                   // out [B n][n2] 16-bit
 };
 extern bool g_st_fuse;
 bool st_entry_eligible(const StEntryArgs& a);
