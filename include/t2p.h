@@ -191,13 +191,15 @@ int t2p_op_small_conv_groupnorm(int dtype, const void* a, const void* w, int64_t
  *   t = a W_in^T + b_in (+ residual);  out2 = LayerNorm(t) W_2^T        (t [batch n][C], out2 [batch n][n2], 16-bit)
  * with a = GroupNorm(x) (statistics from col_stats, the per-64-row column sums of x, [batch n / 64][C][2]) or a = x (col_stats
  * NULL).  Entry of the block: W_in = proj_in, W_2 = to_q | to_k | to_v stacked (n2 = 3 C).  After the self-attention: x = its
- * output, W_in = to_out, residual = t (may alias the output t), W_2 = the cross-attention's to_q (n2 = C).
+ * output, W_in = to_out, residual = t (may alias the output t), W_2 = the cross-attention's to_q (n2 = C).  After the
+ * cross-attention: the same with W_2 = ff.net.0 (n2 = 8 C, rows interleaved (value_j, gate_j), bias b_2) and geglu = 1:
+ * out2 [batch n][4 C] = value * gelu_erf(gate) (model/attention.py:37-64).
  * x, w_in [C][C], w_2 [n2][C], residual in the 16-bit compute dtype.  C = 256, n % 32 == 0 (n % 64 == 0 with col_stats),
  * batch n <= 16384; anything else is refused */
 int t2p_op_st_entry(int dtype, const void* x, const float* col_stats, int groups, const float* gn_gamma, const float* gn_beta,
                     float gn_eps, const void* w_in, const float* b_in, const void* residual, const float* ln_gamma,
-                    const float* ln_beta, float ln_eps, const void* w_2, int n2, void* t, void* out2, int batch, int n, int C,
-                    void* stream);
+                    const float* ln_beta, float ln_eps, const void* w_2, int n2, const float* b_2, int geglu, void* t, void* out2,
+                    int batch, int n, int C, void* stream);
 /* the network's input convolution (pre_conv, ncsnpp.py:230: 3x3, C = 5 or 8 input channels -> nf) straight from the NCHW fp32
  * sample, in fp32 arithmetic: x [batch][C][H][W] fp32; w_tcn [3*3][C][nf] fp32 (tap-major); out NHWC [batch][H][W][nf] in
  * out_dtype.  col_stats (optional; W % 64 == 0, nf | 256): [batch H W / 64][nf][2] fp32 = (sum, sum of squares) of the fp32

@@ -405,9 +405,10 @@ def test_small_map_convolution_kernel_matches_the_split_k_path(stem):
 
 @pytest.mark.parametrize("stem", ["cond_length", "cond_length_inpainting"])
 def test_spatial_transformer_row_chains_match_separate_launches(stem):
-    """Plan switch 39: GroupNorm -> proj_in -> LayerNorm_1 -> q | k | v of every SpatialTransformer block of the C = 256 configurations
-    as one launch over 32-row blocks (st_entry_kernel) instead of four.  Both plans against the reference's full-size scores at the
-    benchmark batch."""
+    """Plan switch 39: the row-wise chains of every SpatialTransformer block of the C = 256 configurations as one launch each over
+    32-row blocks (st_entry_kernel): GroupNorm -> proj_in -> LayerNorm_1 -> q | k | v, and to_out + residual -> LayerNorm_2 -> to_q;
+    with switch 40 also to_out + residual -> LayerNorm_3 -> ff.net.0 (GEGLU) -- a tested option that is off by default (slower).
+    All plans against the reference's full-size scores at the benchmark batch."""
     from text2protein_amd import _lib, synth
     cfg, B0, T, chains = _cfg(stem)
     g = load_golden("full_" + stem)
@@ -422,15 +423,18 @@ def test_spatial_transformer_row_chains_match_separate_launches(stem):
     m16 = _model(cfg, sd, "f16")
     outs = {}
     try:
-        for sw in (0, 1):
-            _lib.check(lib.t2p_debug_set(39, sw))
-            outs[sw] = m16(xs, ls, cs).cpu()
-            assert torch.equal(outs[sw], m16(xs, ls, cs).cpu())
+        for name, sw39, sw40 in (("separate", 0, 0), ("chains", 1, 0), ("chains+tail", 1, 1)):
+            _lib.check(lib.t2p_debug_set(39, sw39))
+            _lib.check(lib.t2p_debug_set(40, sw40))
+            outs[name] = m16(xs, ls, cs).cpu()
+            assert torch.equal(outs[name], m16(xs, ls, cs).cpu())
     finally:
         lib.t2p_debug_set(39, 1)
-    assert not torch.equal(outs[0], outs[1]), "the row-chain kernel did not run"
-    d = rel_l2(outs[1], outs[0])
-    e = {sw: max(rel_l2(outs[sw][s], g["score"][i]) for i, s in enumerate((3, chains - 2))) for sw in (0, 1)}
-    print(f"{stem}: SpatialTransformer row chains vs separate launches: rel-L2 = {d:.3e}; vs reference: separate {e[0]:.3e}, chains {e[1]:.3e}")
-    _record(f"st_chains_{stem}", {"fused_vs_separate": d, "separate_vs_reference": e[0], "fused_vs_reference": e[1]})
-    assert d < F16_SCORE_TOL and e[1] < F16_SCORE_TOL and e[1] < 1.05 * e[0]
+        lib.t2p_debug_set(40, 0)
+    assert not torch.equal(outs["separate"], outs["chains"]) and not torch.equal(outs["chains"], outs["chains+tail"]), "a row-chain kernel did not run"
+    e = {k: max(rel_l2(v[s], g["score"][i]) for i, s in enumerate((3, chains - 2))) for k, v in outs.items()}
+    d = {k: rel_l2(outs[k], outs["separate"]) for k in ("chains", "chains+tail")}
+    print(f"{stem}: SpatialTransformer row chains vs separate launches: rel-L2 = {d}; vs reference: {e}")
+    _record(f"st_chains_{stem}", {"vs_separate": d, "vs_reference": e})
+    for k in ("chains", "chains+tail"):
+        assert d[k] < F16_SCORE_TOL and e[k] < F16_SCORE_TOL and e[k] < 1.05 * e["separate"]

@@ -532,12 +532,13 @@ def test_input_conv_and_its_column_statistics(lib, C, nf, H, W):
 
 @pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("B,n,mode", [(3, 256, "entry"), (2, 64, "entry"), (5, 32, "normed"), (32, 256, "entry"), (1, 1024, "normed"),
-                                      (3, 256, "mid"), (32, 256, "mid"), (4, 64, "mid")])
+                                      (3, 256, "mid"), (32, 256, "mid"), (4, 64, "mid"), (3, 256, "tail"), (32, 256, "tail")])
 def test_spatial_transformer_row_chain(lib, dt, B, n, mode):
     """t2p_op_st_entry: the row-wise chains of a SpatialTransformer block in one launch over 32-row blocks, against the same chain
     in fp64 with the intermediate roundings of the separate launches (a, t, LayerNorm(t) stored in the compute dtype).
     entry: GroupNorm (from the producer's column sums) -> proj_in -> LayerNorm_1 -> q | k | v (model/attention.py:250-256, 208-213);
-    normed: the same with an already normalised input; mid: t += to_out(o) + b -> LayerNorm_2 -> to_q, in place (:211-213, 186-193)."""
+    normed: the same with an already normalised input; mid: t += to_out(o) + b -> LayerNorm_2 -> to_q, in place (:211-213, 186-193);
+    tail: t += to_out(o) + b -> LayerNorm_3 -> ff.net.0 with the GEGLU epilogue (rows interleaved (value, gate), :37-64, 214)."""
     C, G = 256, 32
     td = TDT[dt]
     g = torch.Generator().manual_seed(17 * n + B + len(mode))
@@ -546,9 +547,10 @@ def test_spatial_transformer_row_chain(lib, dt, B, n, mode):
     w_in = (torch.randn(C, C, generator=g) / C ** 0.5).to(td)
     b_in = 0.3 * torch.randn(C, generator=g)
     lg, lb = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
-    n2 = C if mode == "mid" else 3 * C
+    n2 = {"mid": C, "tail": 8 * C}.get(mode, 3 * C)
     w_2 = (torch.randn(n2, C, generator=g) / C ** 0.5).to(td)
-    res = (torch.randn(B, n, C, generator=g) * 2).to(td) if mode == "mid" else None
+    b_2 = 0.3 * torch.randn(n2, generator=g) if mode == "tail" else None
+    res = (torch.randn(B, n, C, generator=g) * 2).to(td) if mode in ("mid", "tail") else None
     xd = x.double()
     csp = None
     if mode == "entry":
@@ -565,11 +567,15 @@ def test_spatial_transformer_row_chain(lib, dt, B, n, mode):
     td_ = t_ref.double()
     ln = ((td_ - td_.mean(-1, keepdim=True)) / torch.sqrt(td_.var(-1, unbiased=False, keepdim=True) + 1e-5) * lg.double() + lb.double()).to(td)
     out2_ref = ln.double() @ w_2.double().T
+    if mode == "tail":
+        u = out2_ref + b_2.double()
+        out2_ref = u[..., 0::2] * torch.nn.functional.gelu(u[..., 1::2])
     # mid: the residual stream is updated in place
     t = dev(res).clone() if res is not None else torch.full((B, n, C), float("nan"), device="cuda", dtype=td)
-    out2 = torch.full((B, n, n2), float("nan"), device="cuda", dtype=td)
+    out2 = torch.full((B, n, n2 // 2 if mode == "tail" else n2), float("nan"), device="cuda", dtype=td)
     args = lambda CC, nn: (dt, P(dev(x)), csp, G, P(dev(gamma)), P(dev(beta)), 1e-6, P(dev(w_in)), P(dev(b_in)), P(t) if res is not None else None,
-                           P(dev(lg)), P(dev(lb)), 1e-5, P(dev(w_2)), n2, P(t), P(out2), B, nn, CC, None)
+                           P(dev(lg)), P(dev(lb)), 1e-5, P(dev(w_2)), n2, P(dev(b_2)) if b_2 is not None else None, int(mode == "tail"),
+                           P(t), P(out2), B, nn, CC, None)
     check(lib, lib.t2p_op_st_entry(*args(C, n)))
     torch.cuda.synchronize()
     tol = 1.5e-3 if dt == 2 else 1.2e-2

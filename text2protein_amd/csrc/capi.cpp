@@ -280,13 +280,13 @@ int t2p_op_small_conv_groupnorm(int dtype, const void* a, const void* w, int64_t
 
 int t2p_op_st_entry(int dtype, const void* x, const float* col_stats, int groups, const float* gn_gamma, const float* gn_beta, float gn_eps,
                     const void* w_in, const float* b_in, const void* residual, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                    const void* w_qkv, int n2, void* t, void* qkv, int batch, int n, int C, void* stream) {
+                    const void* w_qkv, int n2, const float* b2, int geglu, void* t, void* qkv, int batch, int n, int C, void* stream) {
   API_BEGIN
   StEntryArgs e;
   e.dtype = dtype; e.B = batch; e.n = n; e.C = C; e.x = x; e.cstats = col_stats; e.groups = groups; e.gn_gamma = gn_gamma;
   e.gn_beta = gn_beta; e.gn_eps = gn_eps; e.w_in = w_in; e.b_in = b_in; e.ln_gamma = ln_gamma; e.ln_beta = ln_beta; e.ln_eps = ln_eps;
-  e.w_qkv = w_qkv; e.n2 = n2; e.res = residual; e.t = t; e.qkv = qkv;
-  T2P_REQUIRE(st_entry_eligible(e), "st_entry: C = 256, n2 in {C, 3 C}, 16-bit dtype, n % 32 == 0 (64 with column sums), batch n <= 16384");
+  e.w_qkv = w_qkv; e.n2 = n2; e.b2 = b2; e.geglu = geglu; e.res = residual; e.t = t; e.qkv = qkv;
+  T2P_REQUIRE(st_entry_eligible(e), "st_entry: C = 256, n2 in {C, 3 C} (8 C with geglu), 16-bit dtype, n % 32 == 0 (64 with column sums), batch n <= 16384");
   return launch_st_entry(e, (hipStream_t)stream);
   API_END
 }
@@ -528,6 +528,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 36) { t2p::g_small_conv = value != 0; return T2P_OK; }
   if (key == 38) { t2p::g_pre_conv_split = value != 0; return T2P_OK; }
   if (key == 39) { t2p::g_st_fuse = value != 0; return T2P_OK; }
+  if (key == 40) { t2p::g_st_tail = value != 0; return T2P_OK; }
   if (key == 34) { set_gemm_a_norm(value != 0); return T2P_OK; }
   if (key == 32) { g_attn_merged = value != 0; return T2P_OK; }
   if (key == 33) { g_ffpo_merged = value != 0; return T2P_OK; }

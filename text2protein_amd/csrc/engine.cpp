@@ -1099,6 +1099,10 @@ int Engine::attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
 }
 
 // SpatialTransformer.forward with one BasicTransformerBlock (attention.py:208-215, 250-263)
+// plan switch 40: the chain after the cross-attention (to_out + residual -> LayerNorm_3 -> ff.net.0 with GEGLU) on the row-block kernel
+// too.  Off: every workgroup would stream 1.15 MB of weights, and a CU takes in ~41 GB/s (st_entry_kernel's phase stamps): measured
+// 16.83 -> 16.88 ms per step at cfg3 and 10.98 -> 11.03 at cfg5 against the three separate launches.  Kept as a tested option.
+bool g_st_tail = false;
 int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   const int C = x.C, n = x.H * x.W, dt = dtype(), heads = cfg_.n_heads, d = C / heads;
   const size_t es = dtype_size(dt);
@@ -1175,9 +1179,7 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     T2P_TRY(attention(q, C, L.ctx_k, C, L.ctx_vt, ctx_Tpad_, o, B, heads, n, ctx_T_, d, scale, s));
     pool_.put(q);
   }
-  T2P_TRY(linear(o, false, L.a2_out, rows, t, !tl, t, 1.f, s, true, nullptr, tl));
-  // feed-forward with GEGLU
-  T2P_TRY(launch_layernorm(t, L.ln3.gamma, L.ln3.beta, ln, dt, rows, C, 1e-5f, s, tl));
+  // feed-forward with GEGLU.  t += to_out(o) -> LayerNorm_3 -> ff.net.0 (GEGLU): one launch where the row-block kernel applies
   {
     POOL_GET(g, void*, (size_t)rows * 4 * C * es);
     GemmParams p;
@@ -1185,7 +1187,19 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     p.Bw = L.ff1.w; p.ldb = C; p.M = (int)rows; p.N = 8 * C; p.bias_n = L.ff1.b;
     p.C = g; p.c_f32 = 0; p.ldc = 4 * C; p.geglu = 1;
     T2P_TRY(attach_ws(p));
-    if (g_fuse_geglu && gemm_fuses_geglu(p)) {
+    StEntryArgs e;
+    e.dtype = dt; e.B = B; e.n = n; e.C = C; e.x = o; e.w_in = L.a2_out.w; e.b_in = L.a2_out.b; e.res = t;
+    e.ln_gamma = L.ln3.gamma; e.ln_beta = L.ln3.beta; e.ln_eps = 1e-5f; e.w_qkv = L.ff1.w; e.b2 = L.ff1.b; e.n2 = 8 * C; e.geglu = 1;
+    e.t = t; e.qkv = g;
+    const bool tail_chain = tl && qkv_pre && g_st_tail && g_fuse_geglu && gemm_fuses_geglu(p) && L.a2_out.b && L.ff1.b && st_entry_eligible(e);
+    if (tail_chain) {
+      T2P_TRY(launch_st_entry(e, s));
+    } else {
+      T2P_TRY(linear(o, false, L.a2_out, rows, t, !tl, t, 1.f, s, true, nullptr, tl));
+      T2P_TRY(launch_layernorm(t, L.ln3.gamma, L.ln3.beta, ln, dt, rows, C, 1e-5f, s, tl));
+    }
+    if (tail_chain) {
+    } else if (g_fuse_geglu && gemm_fuses_geglu(p)) {
       T2P_TRY(gemm(p, s));                       // value * gelu(gate) in the GEMM epilogue
     } else {
       POOL_GET(u, float*, (size_t)rows * 8 * C * 4);

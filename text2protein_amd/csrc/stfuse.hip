@@ -14,7 +14,8 @@
 //     of a few microseconds), which is what limits the idea to C = 256 and to levels of <= 8192 rows.
 // st_entry_kernel: a = GroupNorm(x) (statistics from the producer's per-64-row column sums, folded in double, or x already
 // normalised) -> t = proj_in(a) + b -> LayerNorm_1(t) -> q | k | v: the first four launches of the block.  The same kernel with a
-// residual and N2 = C is the chain after the self-attention: t += to_out(o) + b -> LayerNorm_2(t) -> to_q of the cross-attention.
+// residual and N2 = C is the chain after the self-attention: t += to_out(o) + b -> LayerNorm_2(t) -> to_q of the cross-attention;
+// with N2 = 8 C, a bias and the GEGLU epilogue the chain after the cross-attention: t += to_out(o) + b -> LayerNorm_3(t) -> ff.net.0.
 #include <algorithm>
 
 #include "t2p_kernels.h"
@@ -67,13 +68,13 @@ constexpr int SF_ROWS = 32;
 #endif
 
 // One stage: out[32][N] = A[32][K] W[N][K]^T with A in LDS (row stride RS bytes), N = 128 TPW.  Wavefront `wave` of 8 takes the TPW
-// column tiles wave, wave + 8, ...; `epi(i, ct, acc)` receives the two row tiles of a finished column tile: acc[rt][e] = row
+// column tiles wave, wave + 8, ...; `epi(i, ct, acc, bias4)` receives the two row tiles of a finished column tile: acc[rt][e] = row
 // 16 rt + (lane & 15), column 16 ct + 4 (lane >> 4) + e.  The weight fragments of a column tile are one L2 round trip away and
 // its matrix work is 16 MFMAs: DEPTH tiles are kept in flight (`ring`, filled by sf_prefetch ahead of the stage: a one-tile
 // look-ahead left the q | k | v stage waiting for every tile: 25.6 us for the whole chain).
 template <typename TC, int K, int RS, int TPW, int DEPTH, typename Epi>
-__device__ __forceinline__ void sf_stage(const unsigned char* a_lds, const TC* W, const int wave, const int lane,
-                                         sf_u32x4 (&ring)[DEPTH][K / 32], Epi&& epi) {
+__device__ __forceinline__ void sf_stage(const unsigned char* a_lds, const TC* W, const float* bias, const int wave, const int lane,
+                                         sf_u32x4 (&ring)[DEPTH][K / 32], float4 (&bring)[DEPTH], Epi&& epi) {
   constexpr int NS = K / 32;
   const int l16 = lane & 15, g4 = lane >> 4;
   sf_u32x4 af[2][NS];
@@ -90,24 +91,29 @@ __device__ __forceinline__ void sf_stage(const unsigned char* a_lds, const TC* W
       SfMma<TC>::run(ring[i % DEPTH][s], af[0][s], acc[0]);
       SfMma<TC>::run(ring[i % DEPTH][s], af[1][s], acc[1]);
     }
+    const float4 bb = bring[i % DEPTH];                     // this tile's bias (the lane's 4 columns; zeros without one)
     if (i + DEPTH < TPW) {                                  // this slot's fragments are consumed: request the tile DEPTH ahead
       const TC* wr = W + (long)((ct + 8 * DEPTH) * 16 + l16) * K + 8 * g4;
 #pragma unroll
       for (int s = 0; s < NS; ++s) ring[i % DEPTH][s] = *(const sf_u32x4*)(wr + 32 * s);
+      if (bias) bring[i % DEPTH] = *(const float4*)(bias + (ct + 8 * DEPTH) * 16 + 4 * g4);
     }
-    epi(i, ct, acc);
+    epi(i, ct, acc, bb);
   }
 }
 // the fragments of this wavefront's first min(DEPTH, TPW) column tiles of W [N][K] (what sf_stage expects in `ring`)
 template <typename TC, int K, int TPW, int DEPTH>
-__device__ __forceinline__ void sf_prefetch(const TC* W, const int wave, const int lane, sf_u32x4 (&ring)[DEPTH][K / 32]) {
+__device__ __forceinline__ void sf_prefetch(const TC* W, const float* bias, const int wave, const int lane, sf_u32x4 (&ring)[DEPTH][K / 32],
+                                            float4 (&bring)[DEPTH]) {
   const int l16 = lane & 15, g4 = lane >> 4;
 #pragma unroll
   for (int i = 0; i < DEPTH; ++i) {
+    bring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < TPW) {
       const TC* wr = W + (long)((wave + 8 * i) * 16 + l16) * K + 8 * g4;
 #pragma unroll
       for (int s = 0; s < K / 32; ++s) ring[i][s] = *(const sf_u32x4*)(wr + 32 * s);
+      if (bias) bring[i] = *(const float4*)(bias + (wave + 8 * i) * 16 + 4 * g4);
     }
   }
 }
@@ -148,7 +154,21 @@ __device__ __forceinline__ void sf_layernorm(unsigned char* buf, const float (&g
   }
 }
 
-template <typename TC, int C, int TPW2>      // TPW2: column tiles of the second product per wavefront (N2 = 128 TPW2: 3 C or C)
+// erf-GELU of the fused GEGLU epilogue: Abramowitz-Stegun 7.1.26 (|error of erf| <= 1.5e-7), as gemm.hip's gelu_erf_fast
+__device__ inline float sf_gelu(float g) {
+  const float x = g * 0.70710678118654752440f, ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  float q = fmaf(t, 1.061405429f, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
+  return 0.5f * g * (1.f + copysignf(fmaf(-q * t, e, 1.f), x));
+}
+
+// TPW2: column tiles of the second product per wavefront (N2 = 128 TPW2: 3 C, C, or 8 C with GEGLU: interleaved (value, gate)
+// columns, out2[row][j] = value_j gelu(gate_j), N2 / 2 columns -- FeedForward's first layer, model/attention.py:37-64)
+template <typename TC, int C, int TPW2, bool GEGLU>
 __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
   constexpr int RS = C * 2 + 16;                             // LDS row stride: an odd number of 16-byte units
   constexpr int NS = C / 32;
@@ -170,7 +190,8 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
   // independent of everything: this wavefront's proj_in fragments (both of its column tiles) and the rows themselves
   constexpr int DEPTH = 3;
   sf_u32x4 ring[DEPTH][NS];
-  sf_prefetch<TC, C, C / 128, DEPTH>(Win, wave, lane, ring);
+  float4 bring[DEPTH];
+  sf_prefetch<TC, C, C / 128, DEPTH>(Win, a.b_in, wave, lane, ring, bring);
   constexpr int XPT = SF_ROWS * (C / 8) / 512;               // 16-byte pieces of the row block per thread
   sf_u32x4 xr[XPT];
   {
@@ -188,9 +209,6 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
   float lga[PER], lbe[PER];
 #pragma unroll
   for (int k = 0; k < PER; ++k) { lga[k] = a.ln_gamma[lane * PER + k]; lbe[k] = a.ln_beta[lane * PER + k]; }
-  float4 bin[C / 128];
-#pragma unroll
-  for (int i = 0; i < C / 128; ++i) bin[i] = *(const float4*)(a.b_in + (wave + 8 * i) * 16 + 4 * g4);
   sf_u32x2 rres[C / 128][2];                                 // residual of the first product: this lane's 4 channels of its two rows per tile
 #pragma unroll
   for (int i = 0; i < C / 128; ++i)
@@ -260,9 +278,8 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
   // ---- t = proj_in(a) + bias: to global memory (the block's residual stream) and to LDS -----------------------------------------
   {
     TC* T = (TC*)a.t;
-    sf_stage<TC, C, RS, C / 128, DEPTH>(bufx, Win, wave, lane, ring, [&](int i, int ct, sf_f32x4 (&acc)[2]) {
+    sf_stage<TC, C, RS, C / 128, DEPTH>(bufx, Win, a.b_in, wave, lane, ring, bring, [&](int i, int ct, sf_f32x4 (&acc)[2], const float4 bb) {
       const int col = ct * 16 + 4 * g4;
-      const float4 bb = bin[i];                              // (i: compile-time after unrolling)
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const int r = rt * 16 + l16;
@@ -275,7 +292,7 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
     });
   }
   SF_STAMP(3)
-  sf_prefetch<TC, C, TPW2, DEPTH>(Wqkv, wave, lane, ring);      // the next stage's first fragments travel during the LayerNorm
+  sf_prefetch<TC, C, TPW2, DEPTH>(Wqkv, a.b2, wave, lane, ring, bring);      // the next stage's first fragments travel during the LayerNorm
   __syncthreads();
   SF_STAMP(4)
   sf_layernorm<TC, C, RS>(buft, lga, lbe, a.ln_eps, wave, lane);
@@ -284,13 +301,18 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
   // ---- q | k | v = LayerNorm_1(t) W_qkv^T (CrossAttention.to_q / to_k / to_v carry no bias) -------------------------------------
   {
     TC* Q = (TC*)a.qkv;
-    sf_stage<TC, C, RS, TPW2, DEPTH>(buft, Wqkv, wave, lane, ring, [&](int i, int ct, sf_f32x4 (&acc)[2]) {
+    sf_stage<TC, C, RS, TPW2, DEPTH>(buft, Wqkv, a.b2, wave, lane, ring, bring, [&](int i, int ct, sf_f32x4 (&acc)[2], const float4 bb) {
       const int col = ct * 16 + 4 * g4;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const int r = rt * 16 + l16;
-        *(sf_u32x2*)(Q + (long)(m0 + r) * (128 * TPW2) + col) =
-            sf_u32x2{sf_pack2<TC>(acc[rt][0], acc[rt][1]), sf_pack2<TC>(acc[rt][2], acc[rt][3])};
+        if constexpr (GEGLU) {
+          *(unsigned*)(Q + (long)(m0 + r) * (64 * TPW2) + (col >> 1)) =
+              sf_pack2<TC>((acc[rt][0] + bb.x) * sf_gelu(acc[rt][1] + bb.y), (acc[rt][2] + bb.z) * sf_gelu(acc[rt][3] + bb.w));
+        } else {
+          *(sf_u32x2*)(Q + (long)(m0 + r) * (128 * TPW2) + col) =
+              sf_u32x2{sf_pack2<TC>(acc[rt][0] + bb.x, acc[rt][1] + bb.y), sf_pack2<TC>(acc[rt][2] + bb.z, acc[rt][3] + bb.w)};
+        }
       }
     });
   }
@@ -301,7 +323,8 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
 bool g_st_fuse = true;      // plan switch 39
 bool st_entry_eligible(const StEntryArgs& a) {
   if (!g_st_fuse || (a.dtype != DT_F16 && a.dtype != DT_BF16) || a.C != 256) return false;
-  if (a.n % SF_ROWS != 0 || (long)a.B * a.n > 16384 || (a.n2 != a.C && a.n2 != 3 * a.C)) return false;
+  if (a.n % SF_ROWS != 0 || (long)a.B * a.n > 16384) return false;
+  if (a.geglu ? a.n2 != 8 * a.C : (a.n2 != a.C && a.n2 != 3 * a.C)) return false;
   if (a.cstats && (a.n % 64 != 0 || a.groups <= 0 || a.C % a.groups != 0)) return false;
   return true;
 }
@@ -309,13 +332,13 @@ int launch_st_entry(const StEntryArgs& a, hipStream_t s) {
   T2P_REQUIRE(st_entry_eligible(a) && a.x && a.w_in && a.b_in && a.ln_gamma && a.ln_beta && a.w_qkv && a.t && a.qkv, "st_entry arguments");
   T2P_REQUIRE(!a.cstats || (a.gn_gamma && a.gn_beta), "st_entry: GroupNorm parameters");
   const dim3 grid((unsigned)((long)a.B * a.n / SF_ROWS));
-  if (a.n2 == 3 * a.C) {
-    if (a.dtype == DT_F16) hipLaunchKernelGGL((st_entry_kernel<f16_t, 256, 6>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((st_entry_kernel<bf16_t, 256, 6>), grid, dim3(512), 0, s, a);
-  } else {
-    if (a.dtype == DT_F16) hipLaunchKernelGGL((st_entry_kernel<f16_t, 256, 2>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((st_entry_kernel<bf16_t, 256, 2>), grid, dim3(512), 0, s, a);
+#define T2P_SF(TPW, GG)                                                                                          \
+  {                                                                                                             \
+    if (a.dtype == DT_F16) hipLaunchKernelGGL((st_entry_kernel<f16_t, 256, TPW, GG>), grid, dim3(512), 0, s, a);  \
+    else hipLaunchKernelGGL((st_entry_kernel<bf16_t, 256, TPW, GG>), grid, dim3(512), 0, s, a);                   \
   }
+  if (a.geglu) T2P_SF(16, true) else if (a.n2 == 3 * a.C) T2P_SF(6, false) else T2P_SF(2, false)
+#undef T2P_SF
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
 }

@@ -184,10 +184,13 @@ struct StEntryArgs {
   const void* res = nullptr;             // optional [B n][C] 16-bit residual of the first product (may be `t` itself: rows are private)
   const void* w_qkv = nullptr;           // [n2][C] 16-bit: to_q | to_k | to_v stacked (n2 = 3 C), or one projection (n2 = C); no bias
   int n2 = 0;
+  const float* b2 = nullptr;             // optional bias of the second product [n2]
+  int geglu = 0;                         // n2 = 8 C interleaved (value, gate) columns -> out2 [B n][n2 / 2] = value * gelu_erf(gate)
   void* t = nullptr;                     // out [B n][C] 16-bit: the block's residual stream
   void* qkv = nullptr;                   // out [B n][n2] 16-bit
 };
 extern bool g_st_fuse;
+extern bool g_st_tail;     // engine.cpp (plan switch 40)
 bool st_entry_eligible(const StEntryArgs& a);
 int launch_st_entry(const StEntryArgs& a, hipStream_t s);
 bool small_conv_eligible(const SmallConvArgs& a);
