@@ -407,8 +407,8 @@ def test_small_map_convolution_kernel_matches_the_split_k_path(stem):
 def test_spatial_transformer_row_chains_match_separate_launches(stem):
     """Plan switch 39: the row-wise chains of every SpatialTransformer block of the C = 256 configurations as one launch each over
     32-row blocks (st_entry_kernel): GroupNorm -> proj_in -> LayerNorm_1 -> q | k | v, and to_out + residual -> LayerNorm_2 -> to_q;
-    with switch 40 also to_out + residual -> LayerNorm_3 -> ff.net.0 (GEGLU) -- a tested option that is off by default (slower).
-    All plans against the reference's full-size scores at the benchmark batch."""
+    with switch 40 (launches of >= 8192 rows: cond_length's 32 chains, not cond_length_inpainting's 16) also to_out + residual ->
+    LayerNorm_3 -> ff.net.0 (GEGLU).  All plans against the reference's full-size scores at the benchmark batch."""
     from text2protein_amd import _lib, synth
     cfg, B0, T, chains = _cfg(stem)
     g = load_golden("full_" + stem)
@@ -430,8 +430,9 @@ def test_spatial_transformer_row_chains_match_separate_launches(stem):
             assert torch.equal(outs[name], m16(xs, ls, cs).cpu())
     finally:
         lib.t2p_debug_set(39, 1)
-        lib.t2p_debug_set(40, 0)
-    assert not torch.equal(outs["separate"], outs["chains"]) and not torch.equal(outs["chains"], outs["chains+tail"]), "a row-chain kernel did not run"
+        lib.t2p_debug_set(40, 1)
+    assert not torch.equal(outs["separate"], outs["chains"]), "the row-chain kernel did not run"
+    assert torch.equal(outs["chains"], outs["chains+tail"]) == (chains * cfg.data.max_res_num ** 2 // 64 < 8192), "tail chain: rows >= 8192 only"
     e = {k: max(rel_l2(v[s], g["score"][i]) for i, s in enumerate((3, chains - 2))) for k, v in outs.items()}
     d = {k: rel_l2(outs[k], outs["separate"]) for k in ("chains", "chains+tail")}
     print(f"{stem}: SpatialTransformer row chains vs separate launches: rel-L2 = {d}; vs reference: {e}")

@@ -287,7 +287,17 @@ int t2p_op_st_entry(int dtype, const void* x, const float* col_stats, int groups
   e.gn_beta = gn_beta; e.gn_eps = gn_eps; e.w_in = w_in; e.b_in = b_in; e.ln_gamma = ln_gamma; e.ln_beta = ln_beta; e.ln_eps = ln_eps;
   e.w_qkv = w_qkv; e.n2 = n2; e.b2 = b2; e.geglu = geglu; e.res = residual; e.t = t; e.qkv = qkv;
   T2P_REQUIRE(st_entry_eligible(e), "st_entry: C = 256, n2 in {C, 3 C} (8 C with geglu), 16-bit dtype, n % 32 == 0 (64 with column sums), batch n <= 16384");
-  return launch_st_entry(e, (hipStream_t)stream);
+  // the kernel reads fragment-major weights (the engine keeps such copies): made on the fly here, the call returns after the stream drained
+  void* fm = nullptr;
+  T2P_HIP_CHECK(hipMalloc(&fm, ((size_t)C * C + (size_t)n2 * C) * 2));
+  void* fm2 = (char*)fm + (size_t)C * C * 2;
+  int rc = launch_sf_frag_major(dtype, w_in, fm, C, C, (hipStream_t)stream);
+  if (rc == T2P_OK) rc = launch_sf_frag_major(dtype, w_qkv, fm2, n2, C, (hipStream_t)stream);
+  e.w_in = fm; e.w_qkv = fm2;
+  if (rc == T2P_OK) rc = launch_st_entry(e, (hipStream_t)stream);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(fm);
+  return rc;
   API_END
 }
 

@@ -613,6 +613,21 @@ int Engine::finalize() {
         l.ff1.K = ci;
       }
       T2P_TRY(upload_linear(t + ".ff.net.2.weight", t + ".ff.net.2.bias", ci, 4 * ci, &l.ff2));
+      if (cfg_.compute_dtype != DT_F32 && ci == 256 && l.a1_qkv.w) {
+        // fragment-major copies of the row-chain kernel's weights (1 KiB contiguous per MFMA fragment)
+        auto fm = [&](const void* w, int N, void** out) -> int {
+          *out = pool_.persistent((size_t)N * ci * 2);
+          if (!*out) return T2P_ERR_HIP;
+          return launch_sf_frag_major(cfg_.compute_dtype, w, *out, N, ci, nullptr);
+        };
+        T2P_TRY(fm(l.proj_in.w, ci, &l.fm_in));
+        T2P_TRY(fm(l.a1_qkv.w, 3 * ci, &l.fm_qkv));
+        T2P_TRY(fm(l.a1_out.w, ci, &l.fm_out1));
+        T2P_TRY(fm(l.a2_q.w, ci, &l.fm_q2));
+        T2P_TRY(fm(l.a2_out.w, ci, &l.fm_out2));
+        T2P_TRY(fm(l.ff1.w, 8 * ci, &l.fm_ff1));
+        T2P_HIP_CHECK(hipStreamSynchronize(nullptr));
+      }
       if (cfg_.compute_dtype != DT_F32 && ci % 64 == 0) {
         const HostTensor* wpo = host(p + ".proj_out.weight", {ci, ci, 1, 1});
         const HostTensor* bpo = host(p + ".proj_out.bias", {ci});
@@ -1100,9 +1115,10 @@ int Engine::attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
 
 // SpatialTransformer.forward with one BasicTransformerBlock (attention.py:208-215, 250-263)
 // plan switch 40: the chain after the cross-attention (to_out + residual -> LayerNorm_3 -> ff.net.0 with GEGLU) on the row-block kernel
-// too.  Off: every workgroup would stream 1.15 MB of weights, and a CU takes in ~41 GB/s (st_entry_kernel's phase stamps): measured
-// 16.83 -> 16.88 ms per step at cfg3 and 10.98 -> 11.03 at cfg5 against the three separate launches.  Kept as a tested option.
-bool g_st_tail = false;
+// too: every workgroup streams 1.15 MB of weights for it, which pays only when the launch fills the chip (>= 8192 rows: cfg3
+// 16.26 -> 16.19 ms per step; at cfg5's 4096 rows 10.53 -> 10.55, so the three separate launches stay there).  With row-major weights
+// (half of every fetched line unused, each line fetched twice) the chain was slower everywhere: 16.83 -> 16.88 ms at cfg3.
+bool g_st_tail = true;
 int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   const int C = x.C, n = x.H * x.W, dt = dtype(), heads = cfg_.n_heads, d = C / heads;
   const size_t es = dtype_size(dt);
@@ -1122,10 +1138,10 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     e.x = normed ? x.pre_norm : (const void*)x.p;
     e.cstats = normed ? nullptr : x.cstats;
     e.gn_gamma = L.gn0.gamma; e.gn_beta = L.gn0.beta; e.groups = L.gn0.G; e.gn_eps = 1e-6f;
-    e.w_in = L.proj_in.w; e.b_in = L.proj_in.b;
+    e.w_in = L.fm_in; e.b_in = L.proj_in.b;
     e.ln_gamma = L.ln1.gamma; e.ln_beta = L.ln1.beta; e.ln_eps = 1e-5f;
-    e.w_qkv = L.a1_qkv.w; e.n2 = 3 * C;
-    if ((normed || x.cstats) && L.proj_in.b && st_entry_eligible(e)) {
+    e.w_qkv = L.fm_qkv; e.n2 = 3 * C;
+    if ((normed || x.cstats) && L.proj_in.b && L.fm_in && st_entry_eligible(e)) {
       qkv_pre = (char*)pool_.get((size_t)rows * 3 * C * es);
       if (!qkv_pre) return T2P_ERR_HIP;
       e.t = t; e.qkv = qkv_pre;
@@ -1167,8 +1183,8 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   {
     POOL_GET(q, void*, (size_t)rows * C * es);
     StEntryArgs e;
-    e.dtype = dt; e.B = B; e.n = n; e.C = C; e.x = o; e.w_in = L.a1_out.w; e.b_in = L.a1_out.b; e.res = t;
-    e.ln_gamma = L.ln2.gamma; e.ln_beta = L.ln2.beta; e.ln_eps = 1e-5f; e.w_qkv = L.a2_q.w; e.n2 = C; e.t = t; e.qkv = q;
+    e.dtype = dt; e.B = B; e.n = n; e.C = C; e.x = o; e.w_in = L.fm_out1; e.b_in = L.a1_out.b; e.res = t;
+    e.ln_gamma = L.ln2.gamma; e.ln_beta = L.ln2.beta; e.ln_eps = 1e-5f; e.w_qkv = L.fm_q2; e.n2 = C; e.t = t; e.qkv = q;
     if (tl && qkv_pre && L.a1_out.b && !L.a2_q.b && st_entry_eligible(e)) {
       T2P_TRY(launch_st_entry(e, s));
     } else {
@@ -1188,10 +1204,10 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     p.C = g; p.c_f32 = 0; p.ldc = 4 * C; p.geglu = 1;
     T2P_TRY(attach_ws(p));
     StEntryArgs e;
-    e.dtype = dt; e.B = B; e.n = n; e.C = C; e.x = o; e.w_in = L.a2_out.w; e.b_in = L.a2_out.b; e.res = t;
-    e.ln_gamma = L.ln3.gamma; e.ln_beta = L.ln3.beta; e.ln_eps = 1e-5f; e.w_qkv = L.ff1.w; e.b2 = L.ff1.b; e.n2 = 8 * C; e.geglu = 1;
+    e.dtype = dt; e.B = B; e.n = n; e.C = C; e.x = o; e.w_in = L.fm_out2; e.b_in = L.a2_out.b; e.res = t;
+    e.ln_gamma = L.ln3.gamma; e.ln_beta = L.ln3.beta; e.ln_eps = 1e-5f; e.w_qkv = L.fm_ff1; e.b2 = L.ff1.b; e.n2 = 8 * C; e.geglu = 1;
     e.t = t; e.qkv = g;
-    const bool tail_chain = tl && qkv_pre && g_st_tail && g_fuse_geglu && gemm_fuses_geglu(p) && L.a2_out.b && L.ff1.b && st_entry_eligible(e);
+    const bool tail_chain = tl && qkv_pre && g_st_tail && rows >= 8192 && L.fm_ff1 && g_fuse_geglu && gemm_fuses_geglu(p) && L.a2_out.b && L.ff1.b && st_entry_eligible(e);
     if (tail_chain) {
       T2P_TRY(launch_st_entry(e, s));
     } else {

@@ -67,7 +67,28 @@ constexpr int SF_ROWS = 32;
 #define SF_STAMPS_OUT(p)
 #endif
 
-// One stage: out[32][N] = A[32][K] W[N][K]^T with A in LDS (row stride RS bytes), N = 128 TPW.  Wavefront `wave` of 8 takes the TPW
+// Weights of the chain kernels are stored FRAGMENT-MAJOR (sf_frag_major_kernel, once per engine): the 16 bytes lane l needs for column
+// tile ct and K-step s sit at ((ct K / 32 + s) 64 + l) 16, so a fragment load is 1 KiB contiguous -- eight whole cache lines.  In the
+// row-major [N][K] layout a load touches 16 lines and uses half of each; the other halves belong to the next K-step's load, by which
+// time a CU streaming 190 KiB through a 16 KiB L1 has dropped them: every line crossed the L2 -> CU path twice.
+template <typename TC>
+__global__ void sf_frag_major_kernel(const TC* W, TC* out, int N, int K) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte piece each
+  const int ns = K / 32;
+  if (i >= (long)(N / 16) * ns * 64) return;
+  const int lane = (int)(i & 63), s = (int)((i >> 6) % ns), ct = (int)((i >> 6) / ns);
+  const sf_u32x4 v = *(const sf_u32x4*)(W + (long)(ct * 16 + (lane & 15)) * K + 32 * s + 8 * (lane >> 4));
+  *(sf_u32x4*)(out + i * 8) = v;
+}
+int launch_sf_frag_major(int dtype, const void* W, void* out, int N, int K, hipStream_t s) {
+  T2P_REQUIRE(W && out && N % 16 == 0 && K % 32 == 0 && (dtype == DT_F16 || dtype == DT_BF16), "frag_major arguments");
+  const long n = (long)(N / 16) * (K / 32) * 64;
+  hipLaunchKernelGGL((sf_frag_major_kernel<f16_t>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const f16_t*)W, (f16_t*)out, N, K);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
+// One stage: out[32][N] = A[32][K] W[N][K]^T with A in LDS (row stride RS bytes), N = 128 TPW; W fragment-major.  Wavefront `wave` of 8 takes the TPW
 // column tiles wave, wave + 8, ...; `epi(i, ct, acc, bias4)` receives the two row tiles of a finished column tile: acc[rt][e] = row
 // 16 rt + (lane & 15), column 16 ct + 4 (lane >> 4) + e.  The weight fragments of a column tile are one L2 round trip away and
 // its matrix work is 16 MFMAs: DEPTH tiles are kept in flight (`ring`, filled by sf_prefetch ahead of the stage: a one-tile
@@ -93,9 +114,9 @@ __device__ __forceinline__ void sf_stage(const unsigned char* a_lds, const TC* W
     }
     const float4 bb = bring[i % DEPTH];                     // this tile's bias (the lane's 4 columns; zeros without one)
     if (i + DEPTH < TPW) {                                  // this slot's fragments are consumed: request the tile DEPTH ahead
-      const TC* wr = W + (long)((ct + 8 * DEPTH) * 16 + l16) * K + 8 * g4;
+      const TC* wr = W + ((long)(ct + 8 * DEPTH) * NS * 64 + lane) * 8;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) ring[i % DEPTH][s] = *(const sf_u32x4*)(wr + 32 * s);
+      for (int s = 0; s < NS; ++s) ring[i % DEPTH][s] = *(const sf_u32x4*)(wr + 512 * s);
       if (bias) bring[i % DEPTH] = *(const float4*)(bias + (ct + 8 * DEPTH) * 16 + 4 * g4);
     }
     epi(i, ct, acc, bb);
@@ -110,9 +131,9 @@ __device__ __forceinline__ void sf_prefetch(const TC* W, const float* bias, cons
   for (int i = 0; i < DEPTH; ++i) {
     bring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < TPW) {
-      const TC* wr = W + (long)((wave + 8 * i) * 16 + l16) * K + 8 * g4;
+      const TC* wr = W + ((long)(wave + 8 * i) * (K / 32) * 64 + lane) * 8;
 #pragma unroll
-      for (int s = 0; s < K / 32; ++s) ring[i][s] = *(const sf_u32x4*)(wr + 32 * s);
+      for (int s = 0; s < K / 32; ++s) ring[i][s] = *(const sf_u32x4*)(wr + 512 * s);
       if (bias) bring[i] = *(const float4*)(bias + (wave + 8 * i) * 16 + 4 * g4);
     }
   }

@@ -179,6 +179,7 @@ struct StEntryArgs {
   const void* x = nullptr;               // [B n][C] 16-bit: the block input (raw with cstats, already normalised without)
   const float* cstats = nullptr;         // per-64-row column sums of x ([B n / 64][C][2]) or null
   const float* gn_gamma = nullptr; const float* gn_beta = nullptr; int groups = 0; float gn_eps = 1e-6f;
+  // the two weight matrices are FRAGMENT-MAJOR copies (launch_sf_frag_major of the row-major [N][K] 16-bit matrices)
   const void* w_in = nullptr; const float* b_in = nullptr;       // proj_in [C][C] 16-bit, bias [C]
   const float* ln_gamma = nullptr; const float* ln_beta = nullptr; float ln_eps = 1e-5f;
   const void* res = nullptr;             // optional [B n][C] 16-bit residual of the first product (may be `t` itself: rows are private)
@@ -193,6 +194,8 @@ extern bool g_st_fuse;
 extern bool g_st_tail;     // engine.cpp (plan switch 40)
 bool st_entry_eligible(const StEntryArgs& a);
 int launch_st_entry(const StEntryArgs& a, hipStream_t s);
+// out = W [N][K] (16-bit, row-major) re-ordered so that every MFMA fragment of 16 rows x 32 K is 1 KiB contiguous (same size)
+int launch_sf_frag_major(int dtype, const void* W, void* out, int N, int K, hipStream_t s);
 bool small_conv_eligible(const SmallConvArgs& a);
 int launch_small_conv_gn(const SmallConvArgs& a, hipStream_t s);
 
