@@ -841,6 +841,17 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
     c1.gn_gamma = c1.groups ? hint.norm->gamma : nullptr; c1.gn_beta = c1.groups ? hint.norm->beta : nullptr;
     if (L.has_conv2) { c1.X0 = a0; c1.X1 = c1.CX1 ? a0 : nullptr; } else { c1.R = a0; }
     if (small_conv_eligible(c0) && small_conv_eligible(c1)) {
+      if (g_small_conv_fm && c0.ldw % 32 == 0 && c1.ldw % 32 == 0) {
+        // fragment-major weight copies (whole cache lines per fragment load), made the first time the block takes this path
+        if (!L.fm_conv0) {
+          L.fm_conv0 = pool_.persistent((size_t)Cout * c0.ldw * 2);
+          L.fm_conv1 = pool_.persistent((size_t)Cout * c1.ldw * 2);
+          if (!L.fm_conv0 || !L.fm_conv1) return T2P_ERR_HIP;
+          T2P_TRY(launch_sf_frag_major(dt, c0.Wt, L.fm_conv0, Cout, (int)c0.ldw, s));
+          T2P_TRY(launch_sf_frag_major(dt, c1.Wt, L.fm_conv1, Cout, (int)c1.ldw, s));
+        }
+        c0.Wt = L.fm_conv0; c0.w_fm = 1; c1.Wt = L.fm_conv1; c1.w_fm = 1;
+      }
       POOL_GET(a1s, void*, (size_t)rows_out * Cout * dtype_size(dt));
       c0.normed = a1s;
       T2P_TRY(launch_small_conv_gn(c0, s));
@@ -1119,6 +1130,7 @@ int Engine::attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
 // 16.26 -> 16.19 ms per step; at cfg5's 4096 rows 10.53 -> 10.55, so the three separate launches stay there).  With row-major weights
 // (half of every fetched line unused, each line fetched twice) the chain was slower everywhere: 16.83 -> 16.88 ms at cfg3.
 bool g_st_tail = true;
+bool g_small_conv_fm = true;   // plan switch 41: the small-map convolution kernel reads fragment-major weight copies
 int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   const int C = x.C, n = x.H * x.W, dt = dtype(), heads = cfg_.n_heads, d = C / heads;
   const size_t es = dtype_size(dt);

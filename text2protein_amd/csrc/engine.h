@@ -59,6 +59,8 @@ struct Layer {
   // blocks with a 1x1 shortcut at the block's own resolution, 16-bit modes: conv1 and the shortcut as one K loop,
   // weights [Cout][9 * Cout + Cin] and bias b1 + b2 (GemmParams::X0)
   DevLinear conv1x;
+  // fragment-major copies of conv0 / conv1 (or conv1x) for the small-map convolution kernel, made at its first use
+  void* fm_conv0 = nullptr; void* fm_conv1 = nullptr;
   bool has_conv2 = false;
   int temb_off = 0;
   // attn (AttnBlockpp): NIN_0|NIN_1 stacked, NIN_2, NIN_3

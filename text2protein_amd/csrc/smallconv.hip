@@ -66,7 +66,11 @@ __global__ __launch_bounds__(512) void small_conv_gn_kernel(const SmallConvArgs 
 
   // ---- everything that depends on nothing is requested FIRST: the first eight weight fragments of this wavefront's K slice and
   // the epilogue's per-channel / per-pixel operands -- a workgroup is a chain of dependent round trips, each one saved counts
-  const TC* wrow = (const TC*)a.Wt + (long)(n0 + l16) * a.ldw + 8 * g4;       // this lane's weight row, its 8-element group
+  // this lane's weight fragments: row-major [N][ldw] (row n0 + l16, 8-element group g4 of a 32-deep step: a load touches half of 16
+  // cache lines) or the fragment-major copy (w_fm: 1 KiB contiguous per step, launch_sf_frag_major: whole lines, twice the intake)
+  const long wstep = a.w_fm ? 512 : 32;
+  const TC* wrow = a.w_fm ? (const TC*)a.Wt + ((long)(n0 >> 4) * (a.ldw >> 5) * 64 + lane) * 8
+                          : (const TC*)a.Wt + (long)(n0 + l16) * a.ldw + 8 * g4;
   constexpr int PF = 8;                                  // weight fragments requested ahead (main K loop): with the accumulators and
   constexpr int PX = 8;                                  // the epilogue operands 119 registers -- 128 is where a CU still holds 2 workgroups
   const int nsteps_main = 9 * (Cmain >> 5);
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(512) void small_conv_gn_kernel(const SmallConvArgs 
   sc_u32x4 wq[PF];
 #pragma unroll
   for (int j = 0; j < PF; ++j)
-    wq[j] = s_lo + j < s_hi ? *(const sc_u32x4*)(wrow + 32L * (s_lo + j)) : sc_u32x4{0u, 0u, 0u, 0u};
+    wq[j] = s_lo + j < s_hi ? *(const sc_u32x4*)(wrow + wstep * (s_lo + j)) : sc_u32x4{0u, 0u, 0u, 0u};
   const bool fin = wave < 4;                             // wavefronts 0 .. 3 finish row tile `wave`; 4 .. 7 only contribute partial sums
   const int tw = wave & 3;
   const int row = m0 + 16 * tw + l16, ch = n0 + 4 * g4;  // this lane's output pixel and its 4 channels
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(512) void small_conv_gn_kernel(const SmallConvArgs 
         const int s = s0 + j;
         if (s < s_hi) {                                  // wave-uniform
           const sc_u32x4 wf = wq[j];
-          if (s + PF < s_hi) wq[j] = *(const sc_u32x4*)(wrow + 32L * (s + PF));
+          if (s + PF < s_hi) wq[j] = *(const sc_u32x4*)(wrow + wstep * (s + PF));
           const int tap = s / cps, cs = s - tap * cps;
           const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
           const int coff = (cs * 32 + 8 * g4) * 2;
@@ -176,20 +180,20 @@ __global__ __launch_bounds__(512) void small_conv_gn_kernel(const SmallConvArgs 
     __syncthreads();
     // (requested here, not before the copy of X: the eight extra live registers there cross the 128-register line below which a
     // CU holds two of these workgroups, and that costs more than the round trip saves -- measured)
-    const TC* wx = wrow + 9L * Cmain;                    // shortcut columns of this lane's weight row
+    const TC* wx = wrow + wstep * (9L * Cmain / 32);     // shortcut columns of this lane's weight row
     const int nsteps_x = Cx >> 5;
     const int x_lo = (nsteps_x * wave) >> 3, x_hi = (nsteps_x * (wave + 1)) >> 3;
     sc_u32x4 xq[PX];
 #pragma unroll
     for (int j = 0; j < PX; ++j)
-      xq[j] = x_lo + j < x_hi ? *(const sc_u32x4*)(wx + 32L * (x_lo + j)) : sc_u32x4{0u, 0u, 0u, 0u};
+      xq[j] = x_lo + j < x_hi ? *(const sc_u32x4*)(wx + wstep * (x_lo + j)) : sc_u32x4{0u, 0u, 0u, 0u};
     for (int s0 = x_lo; s0 < x_hi; s0 += PX) {
 #pragma unroll
       for (int j = 0; j < PX; ++j) {
         const int s = s0 + j;
         if (s < x_hi) {
           const sc_u32x4 wf = xq[j];
-          if (s + PX < x_hi) xq[j] = *(const sc_u32x4*)(wx + 32L * (s + PX));
+          if (s + PX < x_hi) xq[j] = *(const sc_u32x4*)(wx + wstep * (s + PX));
           const int coff = (s * 32 + 8 * g4) * 2;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -302,7 +306,7 @@ bool small_conv_eligible(const SmallConvArgs& a) {
     if (cpg != 8 && cpg != 16) return false;
   }
   if (a.col_stats && HW != 64) return false;
-  if (a.ldw < 9L * a.C + a.CX0 + a.CX1 || a.ldw % 8 != 0) return false;
+  if (a.ldw < 9L * a.C + a.CX0 + a.CX1 || a.ldw % 8 != 0 || (a.w_fm && a.ldw % 32 != 0)) return false;
   // a workgroup is a chain of dependent round trips (rows -> LDS, weights eight steps ahead, reduction): the kernel wins while all
   // its workgroups are resident at once (measured: 512 workgroups at 4 per CU 59.8 -> 49.1 us per block; 1024 at 2 per CU 82 -> 169)
   const int smem = std::max(65 * (Cmax * 2 + 16), 32768) + (128 + 16) * 4;

@@ -154,6 +154,7 @@ struct SmallConvArgs {
   int B = 0, H = 0, W = 0, C = 0, N = 0;
   const void* Wt = nullptr;     // [N][ldw]       16-bit, K index = tap * C + c, then the shortcut columns
   long ldw = 0;
+  int w_fm = 0;                 // Wt is the fragment-major copy of the [N][ldw] matrix (launch_sf_frag_major; ldw % 32 == 0)
   const void* X0 = nullptr; const void* X1 = nullptr;   // optional shortcut sources [B H W][CX0], [B H W][CX1] (16-bit, dense)
   int CX0 = 0, CX1 = 0;
   const float* bias = nullptr;      // [N]
@@ -191,6 +192,7 @@ struct StEntryArgs {
   void* qkv = nullptr;                   // out [B n][n2] 16-bit
 };
 extern bool g_st_fuse;
+extern bool g_small_conv_fm;   // engine.cpp (plan switch 41)
 extern bool g_st_tail;     // engine.cpp (plan switch 40)
 bool st_entry_eligible(const StEntryArgs& a);
 int launch_st_entry(const StEntryArgs& a, hipStream_t s);
