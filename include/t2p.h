@@ -193,13 +193,16 @@ int t2p_op_small_conv_groupnorm(int dtype, const void* a, const void* w, int64_t
  * NULL).  Entry of the block: W_in = proj_in, W_2 = to_q | to_k | to_v stacked (n2 = 3 C).  After the self-attention: x = its
  * output, W_in = to_out, residual = t (may alias the output t), W_2 = the cross-attention's to_q (n2 = C).  After the
  * cross-attention: the same with W_2 = ff.net.0 (n2 = 8 C, rows interleaved (value_j, gate_j), bias b_2) and geglu = 1:
- * out2 [batch n][4 C] = value * gelu_erf(gate) (model/attention.py:37-64).
+ * out2 [batch n][4 C] = value * gelu_erf(gate) (model/attention.py:37-64).  With w_3 [C][5 C] (ff.net.2 and proj_out as one
+ * matrix over [out2 | t], :213-215, 259-263), b_3 and res3 (the block input) a third product follows in the same launch:
+ * y [batch n][C] = [out2 | t] W_3^T + b_3 + res3, y_stats its per-64-row column sums (out2 then stays on chip: out2 may be NULL).
  * x, w_in [C][C], w_2 [n2][C], residual in the 16-bit compute dtype.  C = 256, n % 32 == 0 (n % 64 == 0 with col_stats),
  * batch n <= 16384; anything else is refused */
 int t2p_op_st_entry(int dtype, const void* x, const float* col_stats, int groups, const float* gn_gamma, const float* gn_beta,
                     float gn_eps, const void* w_in, const float* b_in, const void* residual, const float* ln_gamma,
                     const float* ln_beta, float ln_eps, const void* w_2, int n2, const float* b_2, int geglu, void* t, void* out2,
-                    int batch, int n, int C, void* stream);
+                    const void* w_3, const float* b_3, const void* res3, void* y, float* y_stats, int batch, int n, int C,
+                    void* stream);
 /* the network's input convolution (pre_conv, ncsnpp.py:230: 3x3, C = 5 or 8 input channels -> nf) straight from the NCHW fp32
  * sample, in fp32 arithmetic: x [batch][C][H][W] fp32; w_tcn [3*3][C][nf] fp32 (tap-major); out NHWC [batch][H][W][nf] in
  * out_dtype.  col_stats (optional; W % 64 == 0, nf | 256): [batch H W / 64][nf][2] fp32 = (sum, sum of squares) of the fp32

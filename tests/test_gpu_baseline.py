@@ -408,7 +408,8 @@ def test_spatial_transformer_row_chains_match_separate_launches(stem):
     """Plan switch 39: the row-wise chains of every SpatialTransformer block of the C = 256 configurations as one launch each over
     32-row blocks (st_entry_kernel): GroupNorm -> proj_in -> LayerNorm_1 -> q | k | v, and to_out + residual -> LayerNorm_2 -> to_q;
     with switch 40 (launches of >= 8192 rows: cond_length's 32 chains, not cond_length_inpainting's 16) also to_out + residual ->
-    LayerNorm_3 -> ff.net.0 (GEGLU).  All plans against the reference's full-size scores at the benchmark batch."""
+    LayerNorm_3 -> ff.net.0 (GEGLU), with switch 42 the merged ff.net.2 / proj_out product and the block's column sums behind it in the
+    same launch.  All plans against the reference's full-size scores at the benchmark batch."""
     from text2protein_amd import _lib, synth
     cfg, B0, T, chains = _cfg(stem)
     g = load_golden("full_" + stem)
@@ -423,19 +424,23 @@ def test_spatial_transformer_row_chains_match_separate_launches(stem):
     m16 = _model(cfg, sd, "f16")
     outs = {}
     try:
-        for name, sw39, sw40 in (("separate", 0, 0), ("chains", 1, 0), ("chains+tail", 1, 1)):
+        for name, sw39, sw40, sw42 in (("separate", 0, 0, 0), ("chains", 1, 0, 0), ("chains+tail", 1, 1, 0), ("chains+tail3", 1, 1, 1)):
             _lib.check(lib.t2p_debug_set(39, sw39))
             _lib.check(lib.t2p_debug_set(40, sw40))
+            _lib.check(lib.t2p_debug_set(42, sw42))
             outs[name] = m16(xs, ls, cs).cpu()
             assert torch.equal(outs[name], m16(xs, ls, cs).cpu())
     finally:
         lib.t2p_debug_set(39, 1)
         lib.t2p_debug_set(40, 1)
+        lib.t2p_debug_set(42, 1)
     assert not torch.equal(outs["separate"], outs["chains"]), "the row-chain kernel did not run"
-    assert torch.equal(outs["chains"], outs["chains+tail"]) == (chains * cfg.data.max_res_num ** 2 // 64 < 8192), "tail chain: rows >= 8192 only"
+    big = chains * cfg.data.max_res_num ** 2 // 64 >= 8192           # rows of the 16x16 level
+    assert torch.equal(outs["chains"], outs["chains+tail"]) == (not big), "GEGLU chain: rows >= 8192 only"
+    assert torch.equal(outs["chains+tail"], outs["chains+tail3"]) == (not big), "third product: rows >= 8192 only"
     e = {k: max(rel_l2(v[s], g["score"][i]) for i, s in enumerate((3, chains - 2))) for k, v in outs.items()}
-    d = {k: rel_l2(outs[k], outs["separate"]) for k in ("chains", "chains+tail")}
+    d = {k: rel_l2(outs[k], outs["separate"]) for k in ("chains", "chains+tail", "chains+tail3")}
     print(f"{stem}: SpatialTransformer row chains vs separate launches: rel-L2 = {d}; vs reference: {e}")
     _record(f"st_chains_{stem}", {"vs_separate": d, "vs_reference": e})
-    for k in ("chains", "chains+tail"):
+    for k in d:
         assert d[k] < F16_SCORE_TOL and e[k] < F16_SCORE_TOL and e[k] < 1.05 * e["separate"]

@@ -532,13 +532,16 @@ def test_input_conv_and_its_column_statistics(lib, C, nf, H, W):
 
 @pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("B,n,mode", [(3, 256, "entry"), (2, 64, "entry"), (5, 32, "normed"), (32, 256, "entry"), (1, 1024, "normed"),
-                                      (3, 256, "mid"), (32, 256, "mid"), (4, 64, "mid"), (3, 256, "tail"), (32, 256, "tail")])
+                                      (3, 256, "mid"), (32, 256, "mid"), (4, 64, "mid"), (3, 256, "tail"), (32, 256, "tail"),
+                                      (3, 256, "tail3"), (32, 256, "tail3"), (6, 64, "tail3")])
 def test_spatial_transformer_row_chain(lib, dt, B, n, mode):
     """t2p_op_st_entry: the row-wise chains of a SpatialTransformer block in one launch over 32-row blocks, against the same chain
     in fp64 with the intermediate roundings of the separate launches (a, t, LayerNorm(t) stored in the compute dtype).
     entry: GroupNorm (from the producer's column sums) -> proj_in -> LayerNorm_1 -> q | k | v (model/attention.py:250-256, 208-213);
     normed: the same with an already normalised input; mid: t += to_out(o) + b -> LayerNorm_2 -> to_q, in place (:211-213, 186-193);
-    tail: t += to_out(o) + b -> LayerNorm_3 -> ff.net.0 with the GEGLU epilogue (rows interleaved (value, gate), :37-64, 214)."""
+    tail: t += to_out(o) + b -> LayerNorm_3 -> ff.net.0 with the GEGLU epilogue (rows interleaved (value, gate), :37-64, 214);
+    tail3: the same followed by y = [g | t] W_3^T + b_3 + x (ff.net.2 and proj_out as one matrix, :213-215, 259-263) and the per-64-row
+    column sums of y (accumulated by pairs of workgroups)."""
     C, G = 256, 32
     td = TDT[dt]
     g = torch.Generator().manual_seed(17 * n + B + len(mode))
@@ -547,6 +550,9 @@ def test_spatial_transformer_row_chain(lib, dt, B, n, mode):
     w_in = (torch.randn(C, C, generator=g) / C ** 0.5).to(td)
     b_in = 0.3 * torch.randn(C, generator=g)
     lg, lb = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    tail3 = mode == "tail3"
+    if tail3:
+        mode = "tail"
     n2 = {"mid": C, "tail": 8 * C}.get(mode, 3 * C)
     w_2 = (torch.randn(n2, C, generator=g) / C ** 0.5).to(td)
     b_2 = 0.3 * torch.randn(n2, generator=g) if mode == "tail" else None
@@ -573,14 +579,28 @@ def test_spatial_transformer_row_chain(lib, dt, B, n, mode):
     # mid: the residual stream is updated in place
     t = dev(res).clone() if res is not None else torch.full((B, n, C), float("nan"), device="cuda", dtype=td)
     out2 = torch.full((B, n, n2 // 2 if mode == "tail" else n2), float("nan"), device="cuda", dtype=td)
+    w_3 = b_3 = res3 = y = ys = None
+    if tail3:
+        w_3 = (torch.randn(C, 5 * C, generator=g) / (5 * C) ** 0.5).to(td)
+        b_3 = 0.3 * torch.randn(C, generator=g)
+        res3 = (torch.randn(B, n, C, generator=g) * 2).to(td)
+        y = torch.full((B, n, C), float("nan"), device="cuda", dtype=td)
+        ys = torch.full((B * n // 64, C, 2), float("nan"), device="cuda")
     args = lambda CC, nn: (dt, P(dev(x)), csp, G, P(dev(gamma)), P(dev(beta)), 1e-6, P(dev(w_in)), P(dev(b_in)), P(t) if res is not None else None,
                            P(dev(lg)), P(dev(lb)), 1e-5, P(dev(w_2)), n2, P(dev(b_2)) if b_2 is not None else None, int(mode == "tail"),
-                           P(t), P(out2), B, nn, CC, None)
+                           P(t), None if tail3 else P(out2), P(dev(w_3)) if tail3 else None, P(dev(b_3)) if tail3 else None,
+                           P(dev(res3)) if tail3 else None, P(y) if tail3 else None, P(ys) if tail3 else None, B, nn, CC, None)
     check(lib, lib.t2p_op_st_entry(*args(C, n)))
     torch.cuda.synchronize()
     tol = 1.5e-3 if dt == 2 else 1.2e-2
     assert rel_l2(t.float().cpu(), t_ref.double()) < tol
-    assert rel_l2(out2.float().cpu(), out2_ref) < 2 * tol
+    if tail3:
+        y_ref = torch.cat([out2_ref.to(td).double(), t_ref.double()], dim=-1) @ w_3.double().T + b_3.double() + res3.double()
+        assert rel_l2(y.float().cpu(), y_ref) < 2 * tol
+        ch = y_ref.reshape(B * n // 64, 64, C)
+        assert rel_l2(ys[..., 0].cpu(), ch.sum(1)) < 2 * tol and rel_l2(ys[..., 1].cpu(), (ch ** 2).sum(1)) < 2 * tol
+    else:
+        assert rel_l2(out2.float().cpu(), out2_ref) < 2 * tol
     # refused, not silently computed by something else: other channel counts, ragged row blocks
     if csp is None:
         assert lib.t2p_op_st_entry(*args(128, n)) != 0

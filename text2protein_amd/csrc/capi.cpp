@@ -280,20 +280,26 @@ int t2p_op_small_conv_groupnorm(int dtype, const void* a, const void* w, int64_t
 
 int t2p_op_st_entry(int dtype, const void* x, const float* col_stats, int groups, const float* gn_gamma, const float* gn_beta, float gn_eps,
                     const void* w_in, const float* b_in, const void* residual, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                    const void* w_qkv, int n2, const float* b2, int geglu, void* t, void* qkv, int batch, int n, int C, void* stream) {
+                    const void* w_qkv, int n2, const float* b2, int geglu, void* t, void* qkv, const void* w3, const float* b3,
+                    const void* res3, void* y, float* y_stats, int batch, int n, int C, void* stream) {
   API_BEGIN
   StEntryArgs e;
   e.dtype = dtype; e.B = batch; e.n = n; e.C = C; e.x = x; e.cstats = col_stats; e.groups = groups; e.gn_gamma = gn_gamma;
   e.gn_beta = gn_beta; e.gn_eps = gn_eps; e.w_in = w_in; e.b_in = b_in; e.ln_gamma = ln_gamma; e.ln_beta = ln_beta; e.ln_eps = ln_eps;
   e.w_qkv = w_qkv; e.n2 = n2; e.b2 = b2; e.geglu = geglu; e.res = residual; e.t = t; e.qkv = qkv;
+  e.w3 = w3; e.b3 = b3; e.res3 = res3; e.y = y; e.y_stats = y_stats;
   T2P_REQUIRE(st_entry_eligible(e), "st_entry: C = 256, n2 in {C, 3 C} (8 C with geglu), 16-bit dtype, n % 32 == 0 (64 with column sums), batch n <= 16384");
   // the kernel reads fragment-major weights (the engine keeps such copies): made on the fly here, the call returns after the stream drained
   void* fm = nullptr;
-  T2P_HIP_CHECK(hipMalloc(&fm, ((size_t)C * C + (size_t)n2 * C) * 2));
+  T2P_HIP_CHECK(hipMalloc(&fm, ((size_t)C * C + (size_t)n2 * C + (w3 ? (size_t)5 * C * C : 0)) * 2));
   void* fm2 = (char*)fm + (size_t)C * C * 2;
+  void* fm3 = (char*)fm2 + (size_t)n2 * C * 2;
   int rc = launch_sf_frag_major(dtype, w_in, fm, C, C, (hipStream_t)stream);
   if (rc == T2P_OK) rc = launch_sf_frag_major(dtype, w_qkv, fm2, n2, C, (hipStream_t)stream);
+  if (rc == T2P_OK && w3) rc = launch_sf_frag_major(dtype, w3, fm3, C, 5 * C, (hipStream_t)stream);
+  if (rc == T2P_OK && w3 && y_stats && hipMemsetAsync(y_stats, 0, (size_t)batch * n / 64 * C * 2 * 4, (hipStream_t)stream) != hipSuccess) rc = T2P_ERR_HIP;
   e.w_in = fm; e.w_qkv = fm2;
+  if (w3) e.w3 = fm3;
   if (rc == T2P_OK) rc = launch_st_entry(e, (hipStream_t)stream);
   (void)hipStreamSynchronize((hipStream_t)stream);
   (void)hipFree(fm);
@@ -540,6 +546,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 39) { t2p::g_st_fuse = value != 0; return T2P_OK; }
   if (key == 40) { t2p::g_st_tail = value != 0; return T2P_OK; }
   if (key == 41) { t2p::g_small_conv_fm = value != 0; return T2P_OK; }
+  if (key == 42) { t2p::g_st_ffpo = value != 0; return T2P_OK; }
   if (key == 34) { set_gemm_a_norm(value != 0); return T2P_OK; }
   if (key == 32) { g_attn_merged = value != 0; return T2P_OK; }
   if (key == 33) { g_ffpo_merged = value != 0; return T2P_OK; }

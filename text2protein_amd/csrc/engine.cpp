@@ -646,6 +646,12 @@ int Engine::finalize() {
         T2P_TRY(upload_matrix(pool_, m, cfg_.compute_dtype, &l.ffpo.w));
         T2P_TRY(upload_f32(bb, &l.ffpo.b));
         l.ffpo.N = ci; l.ffpo.K = 5 * ci;
+        if (ci == 256 && l.fm_in) {          // fragment-major copy for the row-chain kernel's third product
+          l.fm_ffpo = pool_.persistent((size_t)ci * 5 * ci * 2);
+          if (!l.fm_ffpo) return T2P_ERR_HIP;
+          T2P_TRY(launch_sf_frag_major(cfg_.compute_dtype, l.ffpo.w, l.fm_ffpo, ci, 5 * ci, nullptr));
+          T2P_HIP_CHECK(hipStreamSynchronize(nullptr));
+        }
       }
       T2P_TRY(upload_norm(t + ".norm1", ci, 1, &l.ln1));
       T2P_TRY(upload_norm(t + ".norm2", ci, 1, &l.ln2));
@@ -1130,6 +1136,7 @@ int Engine::attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
 // 16.26 -> 16.19 ms per step; at cfg5's 4096 rows 10.53 -> 10.55, so the three separate launches stay there).  With row-major weights
 // (half of every fetched line unused, each line fetched twice) the chain was slower everywhere: 16.83 -> 16.88 ms at cfg3.
 bool g_st_tail = true;
+bool g_st_ffpo = true;         // plan switch 42: the merged ff.net.2 / proj_out product inside the chain after the cross-attention
 bool g_small_conv_fm = true;   // plan switch 41: the small-map convolution kernel reads fragment-major weight copies
 int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   const int C = x.C, n = x.H * x.W, dt = dtype(), heads = cfg_.n_heads, d = C / heads;
@@ -1143,6 +1150,12 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   const bool qkv_flash = g_qkv_fused && L.a1_qkv.w && g_flash_attention && attention_flash_eligible(dt, d, 3 * C, 3 * C, 3 * C, C);
   // GroupNorm -> proj_in -> LayerNorm_1 -> q | k | v as ONE launch where the row-block kernel applies (stfuse.hip)
   char* qkv_pre = nullptr;
+  // the block's last launch (plan switch 42): to_out + residual -> LayerNorm_3 -> ff.net.0 (GEGLU) -> [g | t] W_ffpo + x in one kernel;
+  // its column sums are accumulated by pairs of workgroups into a buffer the entry kernel zeroes
+  const bool mega = tl && x.lowp && qkv_flash && g_st_tail && g_st_ffpo && g_ffpo_merged && L.fm_ffpo && L.fm_ff1 && rows >= 8192 && n % 64 == 0 &&
+                    g_fuse_geglu && L.a2_out.b && L.ff1.b;
+  float* y2 = nullptr;
+  float* y2_stats = nullptr;
   if (tl && x.lowp && qkv_flash) {
     StEntryArgs e;
     e.dtype = dt; e.B = B; e.n = n; e.C = C;
@@ -1156,6 +1169,15 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     if ((normed || x.cstats) && L.proj_in.b && L.fm_in && st_entry_eligible(e)) {
       qkv_pre = (char*)pool_.get((size_t)rows * 3 * C * es);
       if (!qkv_pre) return T2P_ERR_HIP;
+      if (mega) {
+        y2 = (float*)pool_.get((size_t)rows * C * es);
+        if (!y2) return T2P_ERR_HIP;
+        if (g_fuse_gn_stats) {
+          y2_stats = (float*)pool_.get((size_t)(rows / 64) * C * 2 * 4);
+          if (!y2_stats) return T2P_ERR_HIP;
+          e.zero = y2_stats; e.zero_n = (long)(rows / 64) * C * 2;
+        }
+      }
       e.t = t; e.qkv = qkv_pre;
       T2P_TRY(launch_st_entry(e, s));
       if (normed) { pool_.put(x.pre_norm); x.pre_norm = nullptr; }
@@ -1220,6 +1242,15 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     e.ln_gamma = L.ln3.gamma; e.ln_beta = L.ln3.beta; e.ln_eps = 1e-5f; e.w_qkv = L.fm_ff1; e.b2 = L.ff1.b; e.n2 = 8 * C; e.geglu = 1;
     e.t = t; e.qkv = g;
     const bool tail_chain = tl && qkv_pre && g_st_tail && rows >= 8192 && L.fm_ff1 && g_fuse_geglu && gemm_fuses_geglu(p) && L.a2_out.b && L.ff1.b && st_entry_eligible(e);
+    if (tail_chain && y2) {
+      e.w3 = L.fm_ffpo; e.b3 = L.ffpo.b; e.res3 = x.p; e.y = y2; e.y_stats = y2_stats; e.qkv = nullptr;
+      T2P_REQUIRE(st_entry_eligible(e), "row chain with the third product");
+      T2P_TRY(launch_st_entry(e, s));
+      pool_.put(g); pool_.put(o); pool_.put(ln); pool_.put(t);
+      *out = Act{y2, C, x.H, x.W, y2_stats, true};
+      return T2P_OK;
+    }
+    if (y2) { pool_.put(y2); pool_.put(y2_stats); y2 = nullptr; y2_stats = nullptr; }     // (entry chain taken, tail not: unused)
     if (tail_chain) {
       T2P_TRY(launch_st_entry(e, s));
     } else {

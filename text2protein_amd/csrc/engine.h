@@ -75,7 +75,7 @@ struct Layer {
   // proj_out(t + ff2(g)) = [W_po W_ff2 | W_po] [g ; t] + (W_po b_ff2 + b_po); ffpo.w = [C][4 C + C]
   DevLinear ffpo;
   // C = 256, 16-bit modes: fragment-major copies of proj_in, a1_qkv, a1_out, a2_q, a2_out, ff1 for the row-chain kernel (stfuse.hip)
-  void* fm_in = nullptr; void* fm_qkv = nullptr; void* fm_out1 = nullptr; void* fm_q2 = nullptr; void* fm_out2 = nullptr; void* fm_ff1 = nullptr;
+  void* fm_in = nullptr; void* fm_qkv = nullptr; void* fm_out1 = nullptr; void* fm_q2 = nullptr; void* fm_out2 = nullptr; void* fm_ff1 = nullptr; void* fm_ffpo = nullptr;
   DevNorm ln1, ln2, ln3;
   void* ctx_k = nullptr;   // [B][T][C]      compute dtype (set_context)
   void* ctx_vt = nullptr;  // [B][C][Tpad]   compute dtype

@@ -139,14 +139,15 @@ __device__ __forceinline__ void sf_prefetch(const TC* W, const float* bias, cons
   }
 }
 
-// LayerNorm of the 32 rows of `buf` in place: wavefront w takes rows 4 w .. 4 w + 3, a lane C / 64 consecutive channels
+// LayerNorm of the 32 rows of `src` into `dst` (may be the same): wavefront w takes rows 4 w .. 4 w + 3, a lane C / 64 consecutive channels
 template <typename TC, int C, int RS>
-__device__ __forceinline__ void sf_layernorm(unsigned char* buf, const float (&ga)[C / 64], const float (&be)[C / 64], const float eps,
-                                             const int wave, const int lane) {
+__device__ __forceinline__ void sf_layernorm(const unsigned char* src, unsigned char* dst, const float (&ga)[C / 64], const float (&be)[C / 64],
+                                             const float eps, const int wave, const int lane) {
   constexpr int PER = C / 64;                                // 4 (C = 256) or 8 (C = 512) channels per lane; ga / be: its gamma / beta
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    unsigned char* row = buf + (wave * 4 + r) * RS + lane * PER * 2;
+    const unsigned char* row = src + (wave * 4 + r) * RS + lane * PER * 2;
+    unsigned char* orow = dst + (wave * 4 + r) * RS + lane * PER * 2;
     float v[PER];
     if constexpr (PER == 4) {
       const sf_u32x2 u = *(const sf_u32x2*)row;
@@ -168,9 +169,9 @@ __device__ __forceinline__ void sf_layernorm(unsigned char* buf, const float (&g
 #pragma unroll
     for (int k = 0; k < PER; ++k) y[k] = (v[k] - mean) * rstd * ga[k] + be[k];
     if constexpr (PER == 4) {
-      *(sf_u32x2*)row = sf_u32x2{sf_pack2<TC>(y[0], y[1]), sf_pack2<TC>(y[2], y[3])};
+      *(sf_u32x2*)orow = sf_u32x2{sf_pack2<TC>(y[0], y[1]), sf_pack2<TC>(y[2], y[3])};
     } else {
-      *(sf_u32x4*)row = sf_u32x4{sf_pack2<TC>(y[0], y[1]), sf_pack2<TC>(y[2], y[3]), sf_pack2<TC>(y[4], y[5]), sf_pack2<TC>(y[6], y[7])};
+      *(sf_u32x4*)orow = sf_u32x4{sf_pack2<TC>(y[0], y[1]), sf_pack2<TC>(y[2], y[3]), sf_pack2<TC>(y[4], y[5]), sf_pack2<TC>(y[6], y[7])};
     }
   }
 }
@@ -189,10 +190,17 @@ __device__ inline float sf_gelu(float g) {
 
 // TPW2: column tiles of the second product per wavefront (N2 = 128 TPW2: 3 C, C, or 8 C with GEGLU: interleaved (value, gate)
 // columns, out2[row][j] = value_j gelu(gate_j), N2 / 2 columns -- FeedForward's first layer, model/attention.py:37-64)
-template <typename TC, int C, int TPW2, bool GEGLU>
+// FFPO (with GEGLU): the gated product stays in LDS and a third product follows -- ff.net.2 and proj_out as ONE matrix over [g | t]
+// (Layer::ffpo, attention.py:213-215, 259-263) + bias + the block input as residual -> the block's output y and its per-64-row
+// column sums (two workgroups share a chunk: two atomic adds into a slot the block's entry kernel zeroed -- commutative, so the
+// result does not depend on their order).
+template <typename TC, int C, int TPW2, bool GEGLU, bool FFPO>
 __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
+  static_assert(!FFPO || GEGLU, "the third product follows the GEGLU form");
   constexpr int RS = C * 2 + 16;                             // LDS row stride: an odd number of 16-byte units
+  constexpr int RSG = 4 * C * 2 + 16;                        // row stride of the gated product g [32][4 C]
   constexpr int NS = C / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gbuf[];     // FFPO only: [32][RSG]
   __shared__ __attribute__((aligned(16))) unsigned char bufx[SF_ROWS * RS];
   __shared__ __attribute__((aligned(16))) unsigned char buft[SF_ROWS * RS];
   __shared__ double dred[2][C];
@@ -207,6 +215,9 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
   unsigned long long sf_stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   SF_STAMP(0)
+  if (a.zero) {                                              // (entry kernel of a block whose last kernel accumulates column sums)
+    for (long i = (long)blockIdx.x * 512 + tid; i < a.zero_n; i += (long)gridDim.x * 512) a.zero[i] = 0.f;
+  }
 
   // independent of everything: this wavefront's proj_in fragments (both of its column tiles) and the rows themselves
   constexpr int DEPTH = 3;
@@ -236,6 +247,17 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
       rres[i][rt] = a.res ? *(const sf_u32x2*)((const TC*)a.res + (long)(m0 + rt * 16 + l16) * C + (wave + 8 * i) * 16 + 4 * g4) : sf_u32x2{0u, 0u};
+  float4 b3v[2];
+  sf_u32x2 r3v[2][2];
+  if constexpr (FFPO) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int col = (wave + 8 * i) * 16 + 4 * g4;
+      b3v[i] = *(const float4*)(a.b3 + col);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) r3v[i][rt] = *(const sf_u32x2*)((const TC*)a.res3 + (long)(m0 + rt * 16 + l16) * C + col);
+    }
+  }
   // ---- GroupNorm scale / shift of this sample (gn_apply_cols_kernel's arithmetic: column sums folded in double) ----------------
   if (a.cstats) {
     const int nchunk = a.n >> 6, cpg = C / a.groups;
@@ -316,26 +338,81 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
   sf_prefetch<TC, C, TPW2, DEPTH>(Wqkv, a.b2, wave, lane, ring, bring);      // the next stage's first fragments travel during the LayerNorm
   __syncthreads();
   SF_STAMP(4)
-  sf_layernorm<TC, C, RS>(buft, lga, lbe, a.ln_eps, wave, lane);
+  sf_layernorm<TC, C, RS>(buft, bufx, lga, lbe, a.ln_eps, wave, lane);      // (bufx is free: t itself stays in buft for the third product)
   __syncthreads();
   SF_STAMP(5)
   // ---- q | k | v = LayerNorm_1(t) W_qkv^T (CrossAttention.to_q / to_k / to_v carry no bias) -------------------------------------
   {
     TC* Q = (TC*)a.qkv;
-    sf_stage<TC, C, RS, TPW2, DEPTH>(buft, Wqkv, a.b2, wave, lane, ring, bring, [&](int i, int ct, sf_f32x4 (&acc)[2], const float4 bb) {
+    sf_stage<TC, C, RS, TPW2, DEPTH>(bufx, Wqkv, a.b2, wave, lane, ring, bring, [&](int i, int ct, sf_f32x4 (&acc)[2], const float4 bb) {
       const int col = ct * 16 + 4 * g4;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const int r = rt * 16 + l16;
         if constexpr (GEGLU) {
-          *(unsigned*)(Q + (long)(m0 + r) * (64 * TPW2) + (col >> 1)) =
-              sf_pack2<TC>((acc[rt][0] + bb.x) * sf_gelu(acc[rt][1] + bb.y), (acc[rt][2] + bb.z) * sf_gelu(acc[rt][3] + bb.w));
+          const unsigned gg = sf_pack2<TC>((acc[rt][0] + bb.x) * sf_gelu(acc[rt][1] + bb.y), (acc[rt][2] + bb.z) * sf_gelu(acc[rt][3] + bb.w));
+          if constexpr (FFPO) *(unsigned*)(gbuf + r * RSG + col) = gg;      // (col >> 1) elements = col bytes
+          else *(unsigned*)(Q + (long)(m0 + r) * (64 * TPW2) + (col >> 1)) = gg;
         } else {
           *(sf_u32x2*)(Q + (long)(m0 + r) * (128 * TPW2) + col) =
               sf_u32x2{sf_pack2<TC>(acc[rt][0] + bb.x, acc[rt][1] + bb.y), sf_pack2<TC>(acc[rt][2] + bb.z, acc[rt][3] + bb.w)};
         }
       }
     });
+  }
+  if constexpr (FFPO) {
+    // ---- y = [g | t] W_3^T + b_3 + x: K = 4 C (g, LDS) + C (t, LDS); this wavefront's two column tiles share the A fragments ----------
+    constexpr int NS3 = 5 * C / 32, NSG = 4 * C / 32, D3 = 4;
+    const TC* w0p = (const TC*)a.w3 + ((long)wave * NS3 * 64 + lane) * 8;
+    const TC* w1p = (const TC*)a.w3 + ((long)(wave + 8) * NS3 * 64 + lane) * 8;
+    sf_u32x4 q0[D3], q1[D3];
+#pragma unroll
+    for (int j = 0; j < D3; ++j) { q0[j] = *(const sf_u32x4*)(w0p + 512 * j); q1[j] = *(const sf_u32x4*)(w1p + 512 * j); }
+    __syncthreads();                                         // g is complete
+    sf_f32x4 acc3[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) acc3[i][rt] = sf_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s3 = 0; s3 < NS3; ++s3) {
+      const unsigned char* ab = s3 < NSG ? gbuf + l16 * RSG + (32 * s3 + 8 * g4) * 2 : buft + l16 * RS + (32 * (s3 - NSG) + 8 * g4) * 2;
+      const sf_u32x4 a0 = *(const sf_u32x4*)ab, a1 = *(const sf_u32x4*)(ab + 16 * (s3 < NSG ? RSG : RS));
+      const sf_u32x4 w0 = q0[s3 % D3], w1 = q1[s3 % D3];
+      if (s3 + D3 < NS3) { q0[s3 % D3] = *(const sf_u32x4*)(w0p + 512 * (s3 + D3)); q1[s3 % D3] = *(const sf_u32x4*)(w1p + 512 * (s3 + D3)); }
+      SfMma<TC>::run(w0, a0, acc3[0][0]); SfMma<TC>::run(w0, a1, acc3[0][1]);
+      SfMma<TC>::run(w1, a0, acc3[1][0]); SfMma<TC>::run(w1, a1, acc3[1][1]);
+    }
+    TC* Y = (TC*)a.y;
+    const long chunk = m0 >> 6;                              // n % 64 == 0: global row / 64 is the consumer's chunk index
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int col = (wave + 8 * i) * 16 + 4 * g4;
+      const float bq[4] = {b3v[i].x, b3v[i].y, b3v[i].z, b3v[i].w};
+      float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const sf_u32x2 rr = r3v[i][rt];
+        const float v0 = acc3[i][rt][0] + bq[0] + sf_lo<TC>(rr[0]), v1 = acc3[i][rt][1] + bq[1] + sf_hi<TC>(rr[0]);
+        const float v2 = acc3[i][rt][2] + bq[2] + sf_lo<TC>(rr[1]), v3 = acc3[i][rt][3] + bq[3] + sf_hi<TC>(rr[1]);
+        *(sf_u32x2*)(Y + (long)(m0 + rt * 16 + l16) * C + col) = sf_u32x2{sf_pack2<TC>(v0, v1), sf_pack2<TC>(v2, v3)};
+        cs[0] += v0; cs[1] += v1; cs[2] += v2; cs[3] += v3;
+        cq[0] += v0 * v0; cq[1] += v1 * v1; cq[2] += v2 * v2; cq[3] += v3 * v3;
+      }
+      if (a.y_stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float s1 = cs[e], s2 = cq[e];
+#pragma unroll
+          for (int sh = 1; sh < 16; sh <<= 1) { s1 += __shfl_xor(s1, sh, 64); s2 += __shfl_xor(s2, sh, 64); }
+          if (l16 == 0) {
+            float* dst = a.y_stats + (chunk * C + col + e) * 2;
+            atomicAdd(dst, s1);
+            atomicAdd(dst + 1, s2);
+          }
+        }
+      }
+    }
   }
   SF_STAMP(6)
   SF_STAMPS_OUT(a.qkv)
@@ -346,19 +423,30 @@ bool st_entry_eligible(const StEntryArgs& a) {
   if (!g_st_fuse || (a.dtype != DT_F16 && a.dtype != DT_BF16) || a.C != 256) return false;
   if (a.n % SF_ROWS != 0 || (long)a.B * a.n > 16384) return false;
   if (a.geglu ? a.n2 != 8 * a.C : (a.n2 != a.C && a.n2 != 3 * a.C)) return false;
+  if (a.w3 && (!a.geglu || !a.b3 || !a.res3 || !a.y || (a.y_stats && a.n % 64 != 0))) return false;
   if (a.cstats && (a.n % 64 != 0 || a.groups <= 0 || a.C % a.groups != 0)) return false;
   return true;
 }
 int launch_st_entry(const StEntryArgs& a, hipStream_t s) {
-  T2P_REQUIRE(st_entry_eligible(a) && a.x && a.w_in && a.b_in && a.ln_gamma && a.ln_beta && a.w_qkv && a.t && a.qkv, "st_entry arguments");
+  T2P_REQUIRE(st_entry_eligible(a) && a.x && a.w_in && a.b_in && a.ln_gamma && a.ln_beta && a.w_qkv && a.t, "st_entry arguments");
   T2P_REQUIRE(!a.cstats || (a.gn_gamma && a.gn_beta), "st_entry: GroupNorm parameters");
+  T2P_REQUIRE(a.w3 || a.qkv, "st_entry: output of the second product");
   const dim3 grid((unsigned)((long)a.B * a.n / SF_ROWS));
-#define T2P_SF(TPW, GG)                                                                                          \
-  {                                                                                                             \
-    if (a.dtype == DT_F16) hipLaunchKernelGGL((st_entry_kernel<f16_t, 256, TPW, GG>), grid, dim3(512), 0, s, a);  \
-    else hipLaunchKernelGGL((st_entry_kernel<bf16_t, 256, TPW, GG>), grid, dim3(512), 0, s, a);                   \
+#define T2P_SF(TPW, GG, FF, SMEM)                                                                                        \
+  {                                                                                                                      \
+    if (a.dtype == DT_F16) {                                                                                             \
+      auto kern = st_entry_kernel<f16_t, 256, TPW, GG, FF>;                                                              \
+      if (SMEM) T2P_TRY(ensure_dynamic_lds((const void*)kern, SMEM));                                                    \
+      hipLaunchKernelGGL(kern, grid, dim3(512), SMEM, s, a);                                                             \
+    } else {                                                                                                             \
+      auto kern = st_entry_kernel<bf16_t, 256, TPW, GG, FF>;                                                             \
+      if (SMEM) T2P_TRY(ensure_dynamic_lds((const void*)kern, SMEM));                                                    \
+      hipLaunchKernelGGL(kern, grid, dim3(512), SMEM, s, a);                                                             \
+    }                                                                                                                    \
   }
-  if (a.geglu) T2P_SF(16, true) else if (a.n2 == 3 * a.C) T2P_SF(6, false) else T2P_SF(2, false)
+  constexpr int smem_g = SF_ROWS * (4 * 256 * 2 + 16);
+  if (a.w3) T2P_SF(16, true, true, smem_g) else if (a.geglu) T2P_SF(16, true, false, 0) else if (a.n2 == 3 * a.C) T2P_SF(6, false, false, 0)
+  else T2P_SF(2, false, false, 0)
 #undef T2P_SF
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;

@@ -188,11 +188,16 @@ struct StEntryArgs {
   int n2 = 0;
   const float* b2 = nullptr;             // optional bias of the second product [n2]
   int geglu = 0;                         // n2 = 8 C interleaved (value, gate) columns -> out2 [B n][n2 / 2] = value * gelu_erf(gate)
+  // optional third product (with geglu): y = [out2 | t] W_3^T + b_3 + res3: w3 [C][5 C] fragment-major, res3 / y [B n][C] 16-bit;
+  // out2 then stays on chip (qkv unused).  y_stats: per-64-row column sums of y, ACCUMULATED (zeroed beforehand: `zero` of an earlier launch)
+  const void* w3 = nullptr; const float* b3 = nullptr; const void* res3 = nullptr; void* y = nullptr; float* y_stats = nullptr;
+  float* zero = nullptr; long zero_n = 0;   // optional: this launch zeroes zero[0 .. zero_n)
   void* t = nullptr;                     // out [B n][C] 16-bit: the block's residual stream
   void* qkv = nullptr;                   // out [B n][n2] 16-bit
 };
 extern bool g_st_fuse;
 extern bool g_small_conv_fm;   // engine.cpp (plan switch 41)
+extern bool g_st_ffpo;         // engine.cpp (plan switch 42)
 extern bool g_st_tail;     // engine.cpp (plan switch 40)
 bool st_entry_eligible(const StEntryArgs& a);
 int launch_st_entry(const StEntryArgs& a, hipStream_t s);

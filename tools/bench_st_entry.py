@@ -35,7 +35,7 @@ def main():
 
     def run():
         rc = lib.t2p_op_st_entry(2, P(x), P(cs) if a.stats else None, G, P(gamma), P(beta), 1e-6, P(w_in), P(b_in), None, P(gamma), P(beta), 1e-5,
-                                 P(w_qkv), 3 * Cc, None, 0, P(t), P(qkv), a.B, a.n, Cc, None)
+                                 P(w_qkv), 3 * Cc, None, 0, P(t), P(qkv), None, None, None, None, None, a.B, a.n, Cc, None)
         assert rc == 0, lib.t2p_last_error()
 
     for _ in range(5):
