@@ -547,6 +547,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 40) { t2p::g_st_tail = value != 0; return T2P_OK; }
   if (key == 41) { t2p::g_small_conv_fm = value != 0; return T2P_OK; }
   if (key == 42) { t2p::g_st_ffpo = value != 0; return T2P_OK; }
+  if (key == 43) { t2p::g_st_tail_rows = value; return T2P_OK; }
   if (key == 34) { set_gemm_a_norm(value != 0); return T2P_OK; }
   if (key == 32) { g_attn_merged = value != 0; return T2P_OK; }
   if (key == 33) { g_ffpo_merged = value != 0; return T2P_OK; }

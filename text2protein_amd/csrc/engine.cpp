@@ -1136,6 +1136,9 @@ int Engine::attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
 // 16.26 -> 16.19 ms per step; at cfg5's 4096 rows 10.53 -> 10.55, so the three separate launches stay there).  With row-major weights
 // (half of every fetched line unused, each line fetched twice) the chain was slower everywhere: 16.83 -> 16.88 ms at cfg3.
 bool g_st_tail = true;
+// development key 43: fewest rows for which the block's last chain (with the third product) is taken; without the third product
+// (plan switch 42 off) the chain needs twice as many (measured at cfg5's 4096 rows: +0.02 ms without, -0.06 ms with it)
+int g_st_tail_rows = 4096;
 bool g_st_ffpo = true;         // plan switch 42: the merged ff.net.2 / proj_out product inside the chain after the cross-attention
 bool g_small_conv_fm = true;   // plan switch 41: the small-map convolution kernel reads fragment-major weight copies
 int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
@@ -1152,7 +1155,7 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   char* qkv_pre = nullptr;
   // the block's last launch (plan switch 42): to_out + residual -> LayerNorm_3 -> ff.net.0 (GEGLU) -> [g | t] W_ffpo + x in one kernel;
   // its column sums are accumulated by pairs of workgroups into a buffer the entry kernel zeroes
-  const bool mega = tl && x.lowp && qkv_flash && g_st_tail && g_st_ffpo && g_ffpo_merged && L.fm_ffpo && L.fm_ff1 && rows >= 8192 && n % 64 == 0 &&
+  const bool mega = tl && x.lowp && qkv_flash && g_st_tail && g_st_ffpo && g_ffpo_merged && L.fm_ffpo && L.fm_ff1 && rows >= g_st_tail_rows && n % 64 == 0 &&
                     g_fuse_geglu && L.a2_out.b && L.ff1.b;
   float* y2 = nullptr;
   float* y2_stats = nullptr;
@@ -1241,7 +1244,7 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     e.dtype = dt; e.B = B; e.n = n; e.C = C; e.x = o; e.w_in = L.fm_out2; e.b_in = L.a2_out.b; e.res = t;
     e.ln_gamma = L.ln3.gamma; e.ln_beta = L.ln3.beta; e.ln_eps = 1e-5f; e.w_qkv = L.fm_ff1; e.b2 = L.ff1.b; e.n2 = 8 * C; e.geglu = 1;
     e.t = t; e.qkv = g;
-    const bool tail_chain = tl && qkv_pre && g_st_tail && rows >= 8192 && L.fm_ff1 && g_fuse_geglu && gemm_fuses_geglu(p) && L.a2_out.b && L.ff1.b && st_entry_eligible(e);
+    const bool tail_chain = tl && qkv_pre && g_st_tail && (y2 || rows >= 2 * g_st_tail_rows) && L.fm_ff1 && g_fuse_geglu && gemm_fuses_geglu(p) && L.a2_out.b && L.ff1.b && st_entry_eligible(e);
     if (tail_chain && y2) {
       e.w3 = L.fm_ffpo; e.b3 = L.ffpo.b; e.res3 = x.p; e.y = y2; e.y_stats = y2_stats; e.qkv = nullptr;
       T2P_REQUIRE(st_entry_eligible(e), "row chain with the third product");
