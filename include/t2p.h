@@ -196,8 +196,8 @@ int t2p_op_small_conv_groupnorm(int dtype, const void* a, const void* w, int64_t
  * out2 [batch n][4 C] = value * gelu_erf(gate) (model/attention.py:37-64).  With w_3 [C][5 C] (ff.net.2 and proj_out as one
  * matrix over [out2 | t], :213-215, 259-263), b_3 and res3 (the block input) a third product follows in the same launch:
  * y [batch n][C] = [out2 | t] W_3^T + b_3 + res3, y_stats its per-64-row column sums (out2 then stays on chip: out2 may be NULL).
- * x, w_in [C][C], w_2 [n2][C], residual in the 16-bit compute dtype.  C = 256, n % 32 == 0 (n % 64 == 0 with col_stats),
- * batch n <= 16384; anything else is refused */
+ * x, w_in [C][C], w_2 [n2][C], residual in the 16-bit compute dtype.  C = 256, or C = 512 without geglu / w_3; n % 32 == 0
+ * (n % 64 == 0 with col_stats), batch n <= 8192; anything else is refused */
 int t2p_op_st_entry(int dtype, const void* x, const float* col_stats, int groups, const float* gn_gamma, const float* gn_beta,
                     float gn_eps, const void* w_in, const float* b_in, const void* residual, const float* ln_gamma,
                     const float* ln_beta, float ln_eps, const void* w_2, int n2, const float* b_2, int geglu, void* t, void* out2,

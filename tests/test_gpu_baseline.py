@@ -444,3 +444,36 @@ def test_spatial_transformer_row_chains_match_separate_launches(stem):
     _record(f"st_chains_{stem}", {"vs_separate": d, "vs_reference": e})
     for k in d:
         assert d[k] < F16_SCORE_TOL and e[k] < F16_SCORE_TOL and e[k] < 1.05 * e["separate"]
+
+
+def test_row_chains_at_512_channels():
+    """Plan switch 44 (read when an engine is built): the SpatialTransformer entry and post-self-attention chains on the row-block kernel
+    at C = 512 (test_config's attention levels).  Off by default -- equal step time at cfg2, the chains stream 4x the bytes per workgroup --
+    but kept working: both engines against the reference's full-size scores at the benchmark batch."""
+    from text2protein_amd import _lib, synth
+    stem = "test_config"
+    cfg, B0, T, chains = _cfg(stem)
+    g = load_golden("full_" + stem)
+    sd = synth.synth_state_dict(cfg, 0)
+    x, labels, ctx = full_inputs(cfg, B0, T)
+    xs = torch.from_numpy(synth.normal(79, "filler_x", chains * x[0].numel()).reshape(chains, *x.shape[1:])).cuda() * 20.0
+    cs = synth.synth_context(chains, T, cfg.model.context_dim, 80).cuda()
+    ls = (torch.arange(chains, device="cuda") * 29 + 5) % cfg.model.num_scales
+    for i, s in enumerate((3, chains - 2)):
+        xs[s], cs[s], ls[s] = x[i].cuda(), ctx[i].cuda(), labels[i].cuda()
+    lib = _lib.load()
+    outs = {}
+    try:
+        for sw in (0, 1):
+            _lib.check(lib.t2p_debug_set(44, sw))
+            m16 = _model(cfg, sd, "f16")
+            outs[sw] = m16(xs, ls, cs).cpu()
+            del m16
+    finally:
+        lib.t2p_debug_set(44, 0)
+    assert not torch.equal(outs[0], outs[1]), "the row-chain kernel did not run at C = 512"
+    d = rel_l2(outs[1], outs[0])
+    e = {sw: max(rel_l2(outs[sw][s], g["score"][i]) for i, s in enumerate((3, chains - 2))) for sw in (0, 1)}
+    print(f"{stem}: row chains at C = 512 vs separate launches: rel-L2 = {d:.3e}; vs reference: separate {e[0]:.3e}, chains {e[1]:.3e}")
+    _record("st_chains_512_test_config", {"fused_vs_separate": d, "separate_vs_reference": e[0], "fused_vs_reference": e[1]})
+    assert d < F16_SCORE_TOL and e[1] < F16_SCORE_TOL and e[1] < 1.05 * e[0]

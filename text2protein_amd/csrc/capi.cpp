@@ -288,7 +288,7 @@ int t2p_op_st_entry(int dtype, const void* x, const float* col_stats, int groups
   e.gn_beta = gn_beta; e.gn_eps = gn_eps; e.w_in = w_in; e.b_in = b_in; e.ln_gamma = ln_gamma; e.ln_beta = ln_beta; e.ln_eps = ln_eps;
   e.w_qkv = w_qkv; e.n2 = n2; e.b2 = b2; e.geglu = geglu; e.res = residual; e.t = t; e.qkv = qkv;
   e.w3 = w3; e.b3 = b3; e.res3 = res3; e.y = y; e.y_stats = y_stats;
-  T2P_REQUIRE(st_entry_eligible(e), "st_entry: C = 256, n2 in {C, 3 C} (8 C with geglu), 16-bit dtype, n % 32 == 0 (64 with column sums), batch n <= 16384");
+  T2P_REQUIRE(st_entry_eligible(e), "st_entry: C = 256 (or 512 without geglu), n2 in {C, 3 C} (8 C with geglu), 16-bit dtype, n % 32 == 0 (64 with column sums), batch n <= 8192");
   // the kernel reads fragment-major weights (the engine keeps such copies): made on the fly here, the call returns after the stream drained
   void* fm = nullptr;
   T2P_HIP_CHECK(hipMalloc(&fm, ((size_t)C * C + (size_t)n2 * C + (w3 ? (size_t)5 * C * C : 0)) * 2));
@@ -548,6 +548,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 41) { t2p::g_small_conv_fm = value != 0; return T2P_OK; }
   if (key == 42) { t2p::g_st_ffpo = value != 0; return T2P_OK; }
   if (key == 43) { t2p::g_st_tail_rows = value; return T2P_OK; }
+  if (key == 44) { t2p::g_st_fuse_512 = value != 0; return T2P_OK; }
   if (key == 34) { set_gemm_a_norm(value != 0); return T2P_OK; }
   if (key == 32) { g_attn_merged = value != 0; return T2P_OK; }
   if (key == 33) { g_ffpo_merged = value != 0; return T2P_OK; }

@@ -613,7 +613,9 @@ int Engine::finalize() {
         l.ff1.K = ci;
       }
       T2P_TRY(upload_linear(t + ".ff.net.2.weight", t + ".ff.net.2.bias", ci, 4 * ci, &l.ff2));
-      if (cfg_.compute_dtype != DT_F32 && ci == 256 && l.a1_qkv.w) {
+      // (C = 512: the kernel exists and is tested, but its chains stream 4x the bytes per workgroup: cfg2 51.50 -> 51.50 ms per step
+      // with 100 dispatches fewer, cfg4 equal: taken only with plan switch 44)
+      if (cfg_.compute_dtype != DT_F32 && (ci == 256 || (ci == 512 && g_st_fuse_512)) && l.a1_qkv.w) {
         // fragment-major copies of the row-chain kernel's weights (1 KiB contiguous per MFMA fragment)
         auto fm = [&](const void* w, int N, void** out) -> int {
           *out = pool_.persistent((size_t)N * ci * 2);
@@ -624,8 +626,10 @@ int Engine::finalize() {
         T2P_TRY(fm(l.a1_qkv.w, 3 * ci, &l.fm_qkv));
         T2P_TRY(fm(l.a1_out.w, ci, &l.fm_out1));
         T2P_TRY(fm(l.a2_q.w, ci, &l.fm_q2));
-        T2P_TRY(fm(l.a2_out.w, ci, &l.fm_out2));
-        T2P_TRY(fm(l.ff1.w, 8 * ci, &l.fm_ff1));
+        if (ci == 256) {                        // (the chains through the feed-forward exist at C = 256 only)
+          T2P_TRY(fm(l.a2_out.w, ci, &l.fm_out2));
+          T2P_TRY(fm(l.ff1.w, 8 * ci, &l.fm_ff1));
+        }
         T2P_HIP_CHECK(hipStreamSynchronize(nullptr));
       }
       if (cfg_.compute_dtype != DT_F32 && ci % 64 == 0) {
@@ -1139,6 +1143,7 @@ bool g_st_tail = true;
 // development key 43: fewest rows for which the block's last chain (with the third product) is taken; without the third product
 // (plan switch 42 off) the chain needs twice as many (measured at cfg5's 4096 rows: +0.02 ms without, -0.06 ms with it)
 int g_st_tail_rows = 4096;
+bool g_st_fuse_512 = false;    // plan switch 44 (read when the engine is built): row chains at C = 512 too
 bool g_st_ffpo = true;         // plan switch 42: the merged ff.net.2 / proj_out product inside the chain after the cross-attention
 bool g_small_conv_fm = true;   // plan switch 41: the small-map convolution kernel reads fragment-major weight copies
 int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {

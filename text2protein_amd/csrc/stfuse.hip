@@ -97,20 +97,31 @@ template <typename TC, int K, int RS, int TPW, int DEPTH, typename Epi>
 __device__ __forceinline__ void sf_stage(const unsigned char* a_lds, const TC* W, const float* bias, const int wave, const int lane,
                                          sf_u32x4 (&ring)[DEPTH][K / 32], float4 (&bring)[DEPTH], Epi&& epi) {
   constexpr int NS = K / 32;
+  constexpr bool CACHE = K <= 256;                           // the A fragments of the whole K axis stay in registers (K = 512: re-read per tile)
   const int l16 = lane & 15, g4 = lane >> 4;
-  sf_u32x4 af[2][NS];
+  const unsigned char* const ar = a_lds + l16 * RS + 8 * g4 * 2;
+  sf_u32x4 af[2][CACHE ? NS : 1];
+  if constexpr (CACHE) {
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int s = 0; s < NS; ++s) af[rt][s] = *(const sf_u32x4*)(a_lds + (rt * 16 + l16) * RS + (32 * s + 8 * g4) * 2);
+      for (int s = 0; s < NS; ++s) af[rt][s] = *(const sf_u32x4*)(ar + rt * 16 * RS + 64 * s);
+  }
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
     const int ct = wave + 8 * i;
     sf_f32x4 acc[2] = {sf_f32x4{0.f, 0.f, 0.f, 0.f}, sf_f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      SfMma<TC>::run(ring[i % DEPTH][s], af[0][s], acc[0]);
-      SfMma<TC>::run(ring[i % DEPTH][s], af[1][s], acc[1]);
+      if constexpr (CACHE) {
+        SfMma<TC>::run(ring[i % DEPTH][s], af[0][s], acc[0]);
+        SfMma<TC>::run(ring[i % DEPTH][s], af[1][s], acc[1]);
+      } else {
+        const sf_u32x4 a0 = *(const sf_u32x4*)(ar + 64 * s), a1 = *(const sf_u32x4*)(ar + 16 * RS + 64 * s);
+        SfMma<TC>::run(ring[i % DEPTH][s], a0, acc[0]);
+        SfMma<TC>::run(ring[i % DEPTH][s], a1, acc[1]);
+        if ((s & 3) == 3) asm volatile("" ::: "memory");      // (keeps the compiler from hoisting a whole tile's fragment reads: spills)
+      }
     }
     const float4 bb = bring[i % DEPTH];                     // this tile's bias (the lane's 4 columns; zeros without one)
     if (i + DEPTH < TPW) {                                  // this slot's fragments are consumed: request the tile DEPTH ahead
@@ -200,11 +211,14 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
   constexpr int RS = C * 2 + 16;                             // LDS row stride: an odd number of 16-byte units
   constexpr int RSG = 4 * C * 2 + 16;                        // row stride of the gated product g [32][4 C]
   constexpr int NS = C / 32;
-  extern __shared__ __attribute__((aligned(16))) unsigned char gbuf[];     // FFPO only: [32][RSG]
-  __shared__ __attribute__((aligned(16))) unsigned char bufx[SF_ROWS * RS];
-  __shared__ __attribute__((aligned(16))) unsigned char buft[SF_ROWS * RS];
-  __shared__ double dred[2][C];
-  __shared__ float gsc[C], gsh[C];
+  // LDS (dynamic: 78 KiB at C = 512): the two row buffers, the GroupNorm fold, [FFPO: the gated product g [32][RSG]]
+  extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
+  unsigned char* const bufx = sf_smem;
+  unsigned char* const buft = sf_smem + SF_ROWS * RS;
+  double (*const dred)[C] = (double (*)[C])(sf_smem + 2 * SF_ROWS * RS);
+  float* const gsc = (float*)(sf_smem + 2 * SF_ROWS * RS + 2 * C * 8);
+  float* const gsh = gsc + C;
+  unsigned char* const gbuf = sf_smem + 2 * SF_ROWS * RS + 2 * C * 8 + 2 * C * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, g4 = lane >> 4;
   const int m0 = blockIdx.x * SF_ROWS;
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
   }
 
   // independent of everything: this wavefront's proj_in fragments (both of its column tiles) and the rows themselves
-  constexpr int DEPTH = 3;
+  constexpr int DEPTH = C <= 256 ? 3 : 2;                   // column tiles of weights in flight (C = 512: 2 x 16 KiB per wavefront)
   sf_u32x4 ring[DEPTH][NS];
   float4 bring[DEPTH];
   sf_prefetch<TC, C, C / 128, DEPTH>(Win, a.b_in, wave, lane, ring, bring);
@@ -241,12 +255,16 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
   float lga[PER], lbe[PER];
 #pragma unroll
   for (int k = 0; k < PER; ++k) { lga[k] = a.ln_gamma[lane * PER + k]; lbe[k] = a.ln_beta[lane * PER + k]; }
-  sf_u32x2 rres[C / 128][2];                                 // residual of the first product: this lane's 4 channels of its two rows per tile
+  // residual of the first product: this lane's 4 channels of its two rows per tile (C = 512: loaded in the epilogue, registers)
+  constexpr bool RES_EARLY = C <= 256;
+  sf_u32x2 rres[RES_EARLY ? C / 128 : 1][2];
+  if constexpr (RES_EARLY) {
 #pragma unroll
-  for (int i = 0; i < C / 128; ++i)
+    for (int i = 0; i < C / 128; ++i)
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-      rres[i][rt] = a.res ? *(const sf_u32x2*)((const TC*)a.res + (long)(m0 + rt * 16 + l16) * C + (wave + 8 * i) * 16 + 4 * g4) : sf_u32x2{0u, 0u};
+      for (int rt = 0; rt < 2; ++rt)
+        rres[i][rt] = a.res ? *(const sf_u32x2*)((const TC*)a.res + (long)(m0 + rt * 16 + l16) * C + (wave + 8 * i) * 16 + 4 * g4) : sf_u32x2{0u, 0u};
+  }
   float4 b3v[2];
   sf_u32x2 r3v[2][2];
   if constexpr (FFPO) {
@@ -326,7 +344,9 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const int r = rt * 16 + l16;
-        const sf_u32x2 rr = rres[i][rt];                     // (zeros without a residual)
+        sf_u32x2 rr = sf_u32x2{0u, 0u};                      // (zeros without a residual)
+        if constexpr (RES_EARLY) rr = rres[i][rt];
+        else if (a.res) rr = *(const sf_u32x2*)((const TC*)a.res + (long)(m0 + r) * C + col);
         const sf_u32x2 o = {sf_pack2<TC>(acc[rt][0] + bb.x + sf_lo<TC>(rr[0]), acc[rt][1] + bb.y + sf_hi<TC>(rr[0])),
                             sf_pack2<TC>(acc[rt][2] + bb.z + sf_lo<TC>(rr[1]), acc[rt][3] + bb.w + sf_hi<TC>(rr[1]))};
         *(sf_u32x2*)(buft + r * RS + col * 2) = o;
@@ -421,8 +441,9 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
 
 bool g_st_fuse = true;      // plan switch 39
 bool st_entry_eligible(const StEntryArgs& a) {
-  if (!g_st_fuse || (a.dtype != DT_F16 && a.dtype != DT_BF16) || a.C != 256) return false;
-  if (a.n % SF_ROWS != 0 || (long)a.B * a.n > 16384) return false;
+  if (!g_st_fuse || (a.dtype != DT_F16 && a.dtype != DT_BF16) || (a.C != 256 && a.C != 512)) return false;
+  if (a.C == 512 && (a.geglu || a.w3)) return false;          // (the feed-forward chains stream 4x the bytes there: not built)
+  if (a.n % SF_ROWS != 0 || (long)a.B * a.n > 8192) return false;      // one round of workgroups (two rounds measured slower: cfg4's 32x32 level)
   if (a.geglu ? a.n2 != 8 * a.C : (a.n2 != a.C && a.n2 != 3 * a.C)) return false;
   if (a.w3 && (!a.geglu || !a.b3 || !a.res3 || !a.y || (a.y_stats && a.n % 64 != 0))) return false;
   if (a.cstats && (a.n % 64 != 0 || a.groups <= 0 || a.C % a.groups != 0)) return false;
@@ -433,21 +454,23 @@ int launch_st_entry(const StEntryArgs& a, hipStream_t s) {
   T2P_REQUIRE(!a.cstats || (a.gn_gamma && a.gn_beta), "st_entry: GroupNorm parameters");
   T2P_REQUIRE(a.w3 || a.qkv, "st_entry: output of the second product");
   const dim3 grid((unsigned)((long)a.B * a.n / SF_ROWS));
-#define T2P_SF(TPW, GG, FF, SMEM)                                                                                        \
+#define T2P_SF(CC, TPW, GG, FF)                                                                                          \
   {                                                                                                                      \
+    constexpr int smem = 2 * SF_ROWS * (CC * 2 + 16) + 2 * CC * 8 + 2 * CC * 4 + (FF ? SF_ROWS * (4 * CC * 2 + 16) : 0);  \
     if (a.dtype == DT_F16) {                                                                                             \
-      auto kern = st_entry_kernel<f16_t, 256, TPW, GG, FF>;                                                              \
-      if (SMEM) T2P_TRY(ensure_dynamic_lds((const void*)kern, SMEM));                                                    \
-      hipLaunchKernelGGL(kern, grid, dim3(512), SMEM, s, a);                                                             \
+      auto kern = st_entry_kernel<f16_t, CC, TPW, GG, FF>;                                                               \
+      T2P_TRY(ensure_dynamic_lds((const void*)kern, smem));                                                              \
+      hipLaunchKernelGGL(kern, grid, dim3(512), smem, s, a);                                                             \
     } else {                                                                                                             \
-      auto kern = st_entry_kernel<bf16_t, 256, TPW, GG, FF>;                                                             \
-      if (SMEM) T2P_TRY(ensure_dynamic_lds((const void*)kern, SMEM));                                                    \
-      hipLaunchKernelGGL(kern, grid, dim3(512), SMEM, s, a);                                                             \
+      auto kern = st_entry_kernel<bf16_t, CC, TPW, GG, FF>;                                                              \
+      T2P_TRY(ensure_dynamic_lds((const void*)kern, smem));                                                              \
+      hipLaunchKernelGGL(kern, grid, dim3(512), smem, s, a);                                                             \
     }                                                                                                                    \
   }
-  constexpr int smem_g = SF_ROWS * (4 * 256 * 2 + 16);
-  if (a.w3) T2P_SF(16, true, true, smem_g) else if (a.geglu) T2P_SF(16, true, false, 0) else if (a.n2 == 3 * a.C) T2P_SF(6, false, false, 0)
-  else T2P_SF(2, false, false, 0)
+  if (a.C == 512) {
+    if (a.n2 == 3 * a.C) T2P_SF(512, 12, false, false) else T2P_SF(512, 4, false, false)
+  } else if (a.w3) T2P_SF(256, 16, true, true) else if (a.geglu) T2P_SF(256, 16, true, false) else if (a.n2 == 3 * a.C) T2P_SF(256, 6, false, false)
+  else T2P_SF(256, 2, false, false)
 #undef T2P_SF
   T2P_HIP_CHECK(hipGetLastError());
   return T2P_OK;
