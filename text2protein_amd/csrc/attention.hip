@@ -370,12 +370,17 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(const StripArgs a) {
       key = key < n ? key : n - 1;
       krow[kt] = K + (long)key * a.ldk + 16 * lh;
     }
+#ifdef STRIP_FM_TIMING   // timing only (wrong results): what the loads would cost from a fragment-major K / V^T (1 KiB contiguous per fragment)
+#define KLD(kt, S, j) (*(const uint4*)(K + ((((long)(key_w / 32 + (kt)) * (D / 32) + (S)) * 2 + (j)) * 64 + lane) * 8))
+#else
+#define KLD(kt, S, j) (*(const uint4*)(krow[kt] + 32 * (S) + 8 * (j)))
+#endif
     const unsigned char* qb0 = smem + lr * QRS + 32 * lh;        // query tile 0; tile 1 is 32 rows further
     uint4 ka0[NKT][2], ka1[NKT][2];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      ka0[kt][0] = *(const uint4*)(krow[kt]);
-      ka0[kt][1] = *(const uint4*)(krow[kt] + 8);
+      ka0[kt][0] = KLD(kt, 0, 0);
+      ka0[kt][1] = KLD(kt, 0, 1);
     }
     auto sstep = [&](const uint4 (&ka)[NKT][2], int S) {
       uint4 qf[2][2];
@@ -393,15 +398,15 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(const StripArgs a) {
     for (int S = 0; S < D / 32; S += 2) {                          // D / 32 is even
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) {
-        ka1[kt][0] = *(const uint4*)(krow[kt] + 32 * (S + 1));
-        ka1[kt][1] = *(const uint4*)(krow[kt] + 32 * (S + 1) + 8);
+        ka1[kt][0] = KLD(kt, S + 1, 0);
+        ka1[kt][1] = KLD(kt, S + 1, 1);
       }
       sstep(ka0, S);
       if (S + 2 < D / 32) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-          ka0[kt][0] = *(const uint4*)(krow[kt] + 32 * (S + 2));
-          ka0[kt][1] = *(const uint4*)(krow[kt] + 32 * (S + 2) + 8);
+          ka0[kt][0] = KLD(kt, S + 2, 0);
+          ka0[kt][1] = KLD(kt, S + 2, 1);
         }
       }
       sstep(ka1, S + 1);
@@ -488,7 +493,11 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(const StripArgs a) {
   // V^T fragment of super-step S, step j: keys 32 S + 16 lh + 8 j .. + 7 (whole 8-key chunks are in or out: n % 8 == 0)
   auto vload = [&](int t, int S, int j) -> uint4 {
     const int key = 32 * S + 16 * lh + 8 * j;
+#ifdef STRIP_FM_TIMING
+    return key < n ? *(const uint4*)(VT + ((((long)(ch_w / 32 + t) * ((n + 31) >> 5) + S) * 2 + j) * 64 + lane) * 8) : make_uint4(0, 0, 0, 0);
+#else
     return key < n ? *(const uint4*)(vrow[t] + 32 * S + 8 * j) : make_uint4(0, 0, 0, 0);
+#endif
   };
   uint4 va0[CT][2], va1[CT][2];                                  // two named buffers (a runtime-indexed one would live in scratch)
 #pragma unroll

@@ -21,9 +21,10 @@ def main():
     ap.add_argument("--n", type=int, default=1024)
     ap.add_argument("--d", type=int, default=512)
     ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--lib", default="", help="a measurement build (tools/build_variant.py)")
     a = ap.parse_args()
     from text2protein_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_path(os.path.abspath(a.lib)) if a.lib else _lib.load()
     B, n, d = a.B, a.n, a.d
     qk = torch.randn(B, n, 2 * d, device="cuda").half()
     vt = torch.randn(B, d, n, device="cuda").half()
