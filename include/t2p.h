@@ -239,6 +239,18 @@ int t2p_op_attention(int dtype, const void* q, int64_t ldq, const void* k, int64
 int t2p_op_attention_wide(int dtype, const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt, void* out,
                           int out_f32, const float* bias, const void* residual, int residual_16bit, float alpha, float* col_stats,
                           int batch, int n, int d, float scale, void* stream);
+/* the same with k and vt FRAGMENT-MAJOR ([batch][n d] each: element (r, c) -- r = key, c = channel for k; r = channel, c = key for
+ * vt -- at ((r / 32) (cols / 32) + c / 32) 1024 + ((c / 8) % 2) 512 + ((c / 16) % 2) 256 + (r % 32) 8 + c % 8): the kernel's fragment
+ * loads are then 1 KiB contiguous.  d = 512, 512 < n <= 1024, n % 32 == 0.  Bit-identical to t2p_op_attention_wide. */
+int t2p_op_attention_wide_fm(int dtype, const void* q, int64_t ldq, const void* k_fm, const void* vt_fm, void* out, int out_f32,
+                             const float* bias, const void* residual, int residual_16bit, float alpha, float* col_stats, int batch,
+                             int n, int d, float scale, void* stream);
+/* C = A Bw^T (16-bit, [M][N] row-major; batch > 1: A [M][K] shared, Bw [batch][N][K], C [batch][M][N]) with the columns from
+ * frag_col0 on written fragment-major into c_frag instead (layout above; per sample of rows_per_batch rows, or per batch entry):
+ * what the engine asks of the q | k projection and of the transposed value projection of an AttnBlockpp (layers.py:163-167).
+ * Refused unless the product runs on the 256 x 256 register-epilogue kernel with whole 32 x 32 fragments */
+int t2p_op_gemm_frag_major(int dtype, const void* A, const void* Bw, void* C, void* c_frag, int M, int N, int K, int frag_col0,
+                           int rows_per_batch, int batch, void* stream);
 /* self-attention on the output of ONE stacked projection (CrossAttention.forward with context = x, model/attention.py:
  * 170-191): qkv [batch][n][ld] holds q | k | v in three column blocks of heads*d (head h at column h*d of its block);
  * out [batch][n][heads*d].  V is read row-major -- the fused kernel transposes it on the way out of LDS -- so no

@@ -477,3 +477,38 @@ def test_row_chains_at_512_channels():
     print(f"{stem}: row chains at C = 512 vs separate launches: rel-L2 = {d:.3e}; vs reference: separate {e[0]:.3e}, chains {e[1]:.3e}")
     _record("st_chains_512_test_config", {"fused_vs_separate": d, "separate_vs_reference": e[0], "fused_vs_reference": e[1]})
     assert d < F16_SCORE_TOL and e[1] < F16_SCORE_TOL and e[1] < 1.05 * e[0]
+
+
+@pytest.mark.parametrize("stem", ["test_config", "test_config_large"])
+def test_fragment_major_attention_operands_match_row_major(stem):
+    """Plan switch 45: at the 32 x 32 level of the C = 512 configurations the q | k projection writes its k columns and the transposed
+    value projection all of its output fragment-major, and the wide-head attention kernel streams them with whole cache lines per load.
+    The values are the same ones in another place: bit-identical scores, and both against the reference's full-size scores."""
+    from text2protein_amd import _lib, synth
+    cfg, B0, T, chains = _cfg(stem)
+    g = load_golden("full_" + stem)
+    sd = synth.synth_state_dict(cfg, 0)
+    x, labels, ctx = full_inputs(cfg, B0, T)
+    xs = torch.from_numpy(synth.normal(79, "filler_x", chains * x[0].numel()).reshape(chains, *x.shape[1:])).cuda() * 20.0
+    cs = synth.synth_context(chains, T, cfg.model.context_dim, 80).cuda()
+    ls = (torch.arange(chains, device="cuda") * 29 + 5) % cfg.model.num_scales
+    slots = (3, chains - 2)[:B0]
+    for i, s in enumerate(slots):
+        xs[s], cs[s], ls[s] = x[i].cuda(), ctx[i].cuda(), labels[i].cuda()
+    lib = _lib.load()
+    m16 = _model(cfg, sd, "f16")
+    outs = {}
+    try:
+        for sw in (0, 1):
+            _lib.check(lib.t2p_debug_set(45, sw))
+            lib.t2p_profile_begin()
+            outs[sw] = m16(xs, ls, cs).cpu()
+            o9 = (__import__("ctypes").c_double * 9)()
+            lib.t2p_profile_end(o9)
+    finally:
+        lib.t2p_debug_set(45, 1)
+    e = {sw: max(rel_l2(outs[sw][s], g["score"][i]) for i, s in enumerate(slots)) for sw in (0, 1)}
+    print(f"{stem}: fragment-major attention operands: vs reference: row-major {e[0]:.3e}, fragment-major {e[1]:.3e}; identical: {torch.equal(outs[0], outs[1])}")
+    _record(f"attn_frag_major_{stem}", {"row_major_vs_reference": e[0], "frag_major_vs_reference": e[1], "identical": bool(torch.equal(outs[0], outs[1]))})
+    assert torch.equal(outs[0], outs[1])
+    assert e[1] < F16_SCORE_TOL

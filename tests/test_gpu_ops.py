@@ -610,6 +610,82 @@ def test_spatial_transformer_row_chain(lib, dt, B, n, mode):
         assert lib.t2p_op_st_entry(*args(C, 48)) != 0
 
 
+def _frag_major(x):
+    """[..., R, Ccols] -> the fragment-major order of GemmParams::c_frag (flattened last two dimensions)."""
+    R, Cc = x.shape[-2:]
+    r = torch.arange(R)[:, None].expand(R, Cc)
+    c = torch.arange(Cc)[None, :].expand(R, Cc)
+    idx = ((r // 32) * (Cc // 32) + c // 32) * 1024 + ((c // 8) % 2) * 512 + ((c // 16) % 2) * 256 + (r % 32) * 8 + c % 8
+    out = torch.empty(x.shape[:-2] + (R * Cc,), dtype=x.dtype)
+    out[..., idx.reshape(-1)] = x.reshape(x.shape[:-2] + (R * Cc,))
+    return out
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+def test_gemm_fragment_major_output(lib, dt):
+    """GemmParams::c_frag: the q | k projection of an AttnBlockpp writes its k columns fragment-major per sample, the transposed value
+    projection (batched) all of them -- against the row-major product, element for element."""
+    td = TDT[dt]
+    g = torch.Generator().manual_seed(5)
+    # q | k: 16 samples x 1024 tokens, C = 512
+    Bn, n, C = 16, 1024, 512
+    a = torch.randn(Bn * n, C, generator=g).to(td)
+    w = (torch.randn(2 * C, C, generator=g) / C ** 0.5).to(td)
+    ref = torch.full((Bn * n, 2 * C), float("nan"), device="cuda", dtype=td)          # the same product, row-major, by the same kernel family
+    check(lib, lib.t2p_op_gemm(dt, P(dev(a)), 0, P(dev(w)), P(ref), 0, Bn * n, 2 * C, C, C, C, 2 * C, None, None, 1.0, None))
+    out = torch.full((Bn * n, 2 * C), float("nan"), device="cuda", dtype=td)
+    kf = torch.full((Bn, n * C), float("nan"), device="cuda", dtype=td)
+    check(lib, lib.t2p_op_gemm_frag_major(dt, P(dev(a)), P(dev(w)), P(out), P(kf), Bn * n, 2 * C, C, C, n, 1, None))
+    torch.cuda.synchronize()
+    ref = ref.cpu()
+    assert rel_l2(ref.float(), a.double() @ w.double().T) < (1e-3 if dt == 2 else 6e-3)
+    assert torch.equal(out[:, :C].cpu(), ref[:, :C])
+    assert torch.equal(kf.cpu(), _frag_major(ref[:, C:].reshape(Bn, n, C)))
+    # V^T = W h^T per sample: 32 batch entries, [C][n]
+    Bz = 32
+    h = torch.randn(Bz, n, C, generator=g).to(td)
+    wv = (torch.randn(C, C, generator=g) / C ** 0.5).to(td)
+    refv = wv.double() @ h.double().transpose(1, 2)                            # [Bz][C][n]
+    dummy = torch.full((Bz, C, n), float("nan"), device="cuda", dtype=td)
+    vf = torch.full((Bz, C * n), float("nan"), device="cuda", dtype=td)
+    check(lib, lib.t2p_op_gemm_frag_major(dt, P(dev(wv)), P(dev(h)), P(dummy), P(vf), C, n, C, 0, 1, Bz, None))
+    torch.cuda.synchronize()
+    got = vf.cpu().float()
+    want = _frag_major(refv)
+    assert rel_l2(got, want) < (1e-3 if dt == 2 else 6e-3)
+    assert (got - want.float()).abs().max() < (0.02 if dt == 2 else 0.12)      # (a misplaced element would be off by ~1)
+    # refused where the plan is another one (few tiles), not silently written row-major
+    assert lib.t2p_op_gemm_frag_major(dt, P(dev(a)), P(dev(w)), P(out), P(kf), 4096, 2 * C, C, C, n, 1, None) != 0
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("B,n", [(2, 1024), (3, 640)])
+def test_wide_head_attention_on_fragment_major_operands(lib, dt, B, n):
+    """t2p_op_attention_wide_fm: the same kernel reading K and V^T fragment-major: bit-identical to the row-major form."""
+    td = TDT[dt]
+    d = 512
+    g = torch.Generator().manual_seed(n + dt)
+    qk = torch.randn(B, n, 2 * d, generator=g).to(td)
+    vt = torch.randn(B, d, n, generator=g).to(td)
+    bias = torch.randn(d, generator=g)
+    res = torch.randn(B, n, d, generator=g).to(td)
+    outs = []
+    for fm in (0, 1):
+        out = torch.full((B, n, d), float("nan"), device="cuda", dtype=td)
+        cs = torch.full((B * n // 64, d, 2), float("nan"), device="cuda")
+        qd = dev(qk)
+        if fm:
+            check(lib, lib.t2p_op_attention_wide_fm(dt, P(qd), 2 * d, P(dev(_frag_major(qk[..., d:].contiguous()))), P(dev(_frag_major(vt))), P(out), 0,
+                                                    P(dev(bias)), P(dev(res)), 1, 0.7071, P(cs), B, n, d, d ** -0.5, None))
+        else:
+            check(lib, lib.t2p_op_attention_wide(dt, P(qd), 2 * d, C.c_void_p(qd.data_ptr() + 2 * d), 2 * d, P(dev(vt)), n, P(out), 0, P(dev(bias)),
+                                                 P(dev(res)), 1, 0.7071, P(cs), B, n, d, d ** -0.5, None))
+        torch.cuda.synchronize()
+        outs.append((out.cpu(), cs.cpu()))
+    assert torch.isfinite(outs[0][0].float()).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_input_conv_split_operands_keep_fp32_accuracy(lib):
     """The split form of pre_conv (x = hi + lo / 2048 in f16, three partial products on v_mfma_f32_16x16x32_f16) at the
     magnitudes of a VE run: a prior sample (sigma_max = 100), a late sample (values in [-1, 1] + 0.01 noise), exact zeros of a

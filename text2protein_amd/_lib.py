@@ -68,6 +68,8 @@ SIGNATURES = {
     "t2p_op_conv3x3_groupnorm": (_i, [_i, _vp, _vp, _vp, _vp, _vp, C.c_float, _i, _i, _vp, _vp, C.c_float, _i, _vp, _i, _vp, _vp,
                                       _i, _i, _i, _i, _i, _vp]),
     "t2p_op_attention_wide": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _vp, _vp, _i, _f, _vp, _i, _i, _i, _f, _vp]),
+    "t2p_op_attention_wide_fm": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _i, _i, _i, _f, _vp]),
+    "t2p_op_gemm_frag_major": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2p_op_small_conv_groupnorm": (_i, [_i, _vp, _vp, _i64, _vp, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _i,
                                          _i, _i, _i, _i, _i, _vp]),
     "t2p_op_st_entry": (_i, [_i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -320,7 +320,9 @@ struct StripArgs {
   float* col_stats;
 };
 
-template <typename TC, int D, int NKT>      // NKT: 32-key tiles per wavefront (n <= 256 NKT)
+// FM: K and V^T are FRAGMENT-MAJOR (GemmParams::c_frag of the two projections): a fragment load is 1 KiB contiguous -- eight whole
+// cache lines -- instead of 32 bytes of each of 32 lines (156 -> 105 us per launch at cfg2's 32 x 32 level; n % 32 == 0)
+template <typename TC, int D, int NKT, bool FM = false>      // NKT: 32-key tiles per wavefront (n <= 256 NKT)
 __global__ __launch_bounds__(512) void attn_strip_kernel(const StripArgs a) {
   constexpr int QRS = D * 2 + 16;            // query strip row stride (bytes): consecutive rows 4 banks apart
   constexpr int KW = NKT * 32;               // keys per wavefront
@@ -370,10 +372,11 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(const StripArgs a) {
       key = key < n ? key : n - 1;
       krow[kt] = K + (long)key * a.ldk + 16 * lh;
     }
-#ifdef STRIP_FM_TIMING   // timing only (wrong results): what the loads would cost from a fragment-major K / V^T (1 KiB contiguous per fragment)
+#if defined(STRIP_FM_TIMING)   // timing only (wrong results): the first measurement of what fragment-major operands would give
 #define KLD(kt, S, j) (*(const uint4*)(K + ((((long)(key_w / 32 + (kt)) * (D / 32) + (S)) * 2 + (j)) * 64 + lane) * 8))
 #else
-#define KLD(kt, S, j) (*(const uint4*)(krow[kt] + 32 * (S) + 8 * (j)))
+#define KLD(kt, S, j) (FM ? *(const uint4*)(K + ((((long)(key_w / 32 + (kt)) * (D / 32) + (S)) * 2 + (j)) * 64 + lane) * 8) \
+                          : *(const uint4*)(krow[kt] + 32 * (S) + 8 * (j)))
 #endif
     const unsigned char* qb0 = smem + lr * QRS + 32 * lh;        // query tile 0; tile 1 is 32 rows further
     uint4 ka0[NKT][2], ka1[NKT][2];
@@ -496,6 +499,7 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(const StripArgs a) {
 #ifdef STRIP_FM_TIMING
     return key < n ? *(const uint4*)(VT + ((((long)(ch_w / 32 + t) * ((n + 31) >> 5) + S) * 2 + j) * 64 + lane) * 8) : make_uint4(0, 0, 0, 0);
 #else
+    if constexpr (FM) return *(const uint4*)(VT + ((((long)(ch_w / 32 + t) * (n >> 5) + S) * 2 + j) * 64 + lane) * 8);     // n % 32 == 0
     return key < n ? *(const uint4*)(vrow[t] + 32 * S + 8 * j) : make_uint4(0, 0, 0, 0);
 #endif
   };
@@ -608,12 +612,12 @@ bool attention_strip_eligible(int dtype, int heads, int nq, int nk, int d, long 
   return ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldvt >= nk && ldo % 4 == 0;
 }
 
-template <typename TC, int D, int NKT>
+template <typename TC, int D, int NKT, bool FM = false>
 static int launch_strip_t(const StripArgs& a, int B, hipStream_t s) {
   constexpr int QB = 64 * (D * 2 + 16), PB = 64 * (NKT * 32 * 8 * 2 + 16);
   constexpr int smem = (QB > PB ? QB : PB) + 2 * 8 * 64 * 4;
   static_assert(smem <= 160 * 1024, "attn_strip: LDS budget");
-  auto kern = attn_strip_kernel<TC, D, NKT>;
+  auto kern = attn_strip_kernel<TC, D, NKT, FM>;
   T2P_TRY(ensure_dynamic_lds((const void*)kern, smem));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof_on()) {
@@ -630,6 +634,9 @@ static int launch_strip_t(const StripArgs& a, int B, hipStream_t s) {
   return T2P_OK;
 }
 
+bool attention_strip_frag_major_ok(int dtype, int n, int d) {
+  return (dtype == DT_F16 || dtype == DT_BF16) && d == 512 && n > 512 && n <= 1024 && n % 32 == 0;
+}
 int launch_attention_strip(int dtype, const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
                            int B, int n, int d, float scale, hipStream_t s, const StripEpilogue* ep) {
   T2P_REQUIRE(attention_strip_eligible(dtype, 1, n, n, d, ldq, ldk, ldvt, ldo), "wide-head attention: unsupported shape");
@@ -652,6 +659,12 @@ int launch_attention_strip(int dtype, const void* q, long ldq, const void* k, lo
     a.col_stats = ep->col_stats;
   }
   const int nkt = n <= 256 ? 1 : (n <= 512 ? 2 : 4);
+  if (ep && ep->frag_major) {     // K and V^T fragment-major: [B][n d] each (the 32 x 32 level of the C = 512 configurations)
+    T2P_REQUIRE(attention_strip_frag_major_ok(dtype, n, d), "wide-head attention: fragment-major operands need d = 512, 512 < n <= 1024, n % 32 == 0");
+    a.sk_b = (long)n * d; a.svt_b = (long)n * d;
+    if (dtype == DT_BF16) return launch_strip_t<bf16_t, 512, 4, true>(a, B, s);
+    return launch_strip_t<f16_t, 512, 4, true>(a, B, s);
+  }
 #define T2P_STRIP(TC, DD)                                                        \
   do {                                                                           \
     if (nkt == 1) return launch_strip_t<TC, DD, 1>(a, B, s);                     \

@@ -432,6 +432,34 @@ int t2p_op_attention_wide(int dtype, const void* q, int64_t ldq, const void* k, 
   API_END
 }
 
+int t2p_op_attention_wide_fm(int dtype, const void* q, int64_t ldq, const void* k_fm, const void* vt_fm, void* out, int out_f32,
+                             const float* bias, const void* residual, int residual_16bit, float alpha, float* col_stats, int batch, int n,
+                             int d, float scale, void* stream) {
+  API_BEGIN
+  T2P_REQUIRE(attention_strip_frag_major_ok(dtype, n, d) && attention_strip_eligible(dtype, 1, n, n, d, ldq, d, n, d),
+              "attention_wide_fm: 16-bit dtypes, d = 512, 512 < n <= 1024, n % 32 == 0");
+  StripEpilogue ep;
+  ep.bias = bias; ep.residual = residual; ep.r_lowp = residual_16bit; ep.ldr = d; ep.alpha = alpha; ep.out_f32 = out_f32; ep.col_stats = col_stats;
+  ep.frag_major = 1;
+  return launch_attention_strip(dtype, q, ldq, k_fm, d, vt_fm, n, out, d, batch, n, d, scale, (hipStream_t)stream, &ep);
+  API_END
+}
+
+int t2p_op_gemm_frag_major(int dtype, const void* A, const void* Bw, void* C, void* c_frag, int M, int N, int K, int frag_col0,
+                           int rows_per_batch, int batch, void* stream) {
+  API_BEGIN
+  GemmParams p;
+  p.dtype = dtype; p.A0 = A; p.a_f32 = 0; p.C0 = K; p.lda0 = K; p.Bw = Bw; p.ldb = K; p.M = M; p.N = N;
+  p.C = C; p.c_f32 = 0; p.ldc = N;
+  if (batch > 1) { p.nz0 = batch; p.sA_z0 = 0; p.sB_z0 = (long)N * K; p.sC_z0 = (long)M * N; p.frag_bstride = (long)M * (N - frag_col0); }
+  else { p.rows_per_batch = rows_per_batch; p.frag_bstride = (long)rows_per_batch * (N - frag_col0); }
+  p.c_frag = c_frag; p.frag_col0 = frag_col0; p.frag_ns = (N - frag_col0) / 32;
+  T2P_TRY(attach_op_ws(p));
+  T2P_REQUIRE(gemm_writes_frag_major(p), "gemm_frag_major: the product does not take the fragment-major output (256 x 256 plan, whole fragments)");
+  return launch_gemm(p, (hipStream_t)stream);
+  API_END
+}
+
 int t2p_op_attention_qkv(int dtype, const void* qkv, int64_t ld, void* out, int batch, int heads, int n, int d, float scale, void* stream) {
   API_BEGIN
   const long C = (long)heads * d;
@@ -549,6 +577,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 42) { t2p::g_st_ffpo = value != 0; return T2P_OK; }
   if (key == 43) { t2p::g_st_tail_rows = value; return T2P_OK; }
   if (key == 44) { t2p::g_st_fuse_512 = value != 0; return T2P_OK; }
+  if (key == 45) { t2p::g_attn_fm = value != 0; return T2P_OK; }
   if (key == 34) { set_gemm_a_norm(value != 0); return T2P_OK; }
   if (key == 32) { g_attn_merged = value != 0; return T2P_OK; }
   if (key == 33) { g_ffpo_merged = value != 0; return T2P_OK; }

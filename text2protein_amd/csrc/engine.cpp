@@ -1093,17 +1093,48 @@ int Engine::attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   void* a = nullptr;
   T2P_TRY(group_norm(x, nullptr, L.gn0, 1e-6f, 0, 0, B, &a, s));
   POOL_GET(qk, char*, (size_t)rows * 2 * C * es);
-  T2P_TRY(linear(a, false, L.qk, rows, qk, false, nullptr, 1.f, s));
-  POOL_GET(vt, void*, (size_t)B * C * npad * es);
   const bool olp = res_lowp();
+  const bool merged = g_attn_merged && L.v3.w && attention_strip_eligible(dt, 1, n, n, C, 2 * C, 2 * C, npad, C) && (!x.lowp || olp);
+  // q | k projection; where the wide-head attention kernel takes fragment-major operands (plan switch 45: the 32 x 32 level of the
+  // C = 512 configurations) the k columns and the transposed values are written that way by the products' epilogues
+  GemmParams pq;
+  pq.dtype = dt; pq.A0 = a; pq.a_f32 = dt == DT_F32; pq.C0 = C; pq.lda0 = C; pq.Bw = L.qk.w; pq.ldb = C; pq.M = (int)rows; pq.N = 2 * C;
+  pq.bias_n = L.qk.b; pq.C = qk; pq.c_f32 = 0; pq.ldc = 2 * C;
+  T2P_TRY(attach_ws(pq));
+  void* kfm = nullptr;
+  GemmParams pv;      // the transposed value projection of the merged path (project_vt's parameters), probed for the same option
+  pv.dtype = dt; pv.a_f32 = dt == DT_F32; pv.A0 = L.v3.w; pv.C0 = C; pv.lda0 = C; pv.M = C; pv.N = n; pv.Bw = a; pv.ldb = C;
+  pv.nz0 = B; pv.sA_z0 = 0; pv.sB_z0 = (long)n * C; pv.c_f32 = 0; pv.ldc = npad; pv.sC_z0 = (long)C * npad;
+  T2P_TRY(attach_ws(pv));
+  bool fm = false;
+  if (merged && g_attn_fm && npad == n && attention_strip_frag_major_ok(dt, n, C)) {
+    GemmParams tq = pq, tv = pv;
+    tq.rows_per_batch = n; tq.frag_col0 = C; tq.frag_ns = C / 32; tq.frag_bstride = (long)n * C; tq.c_frag = qk;     // (placeholder pointers)
+    tv.frag_col0 = 0; tv.frag_ns = n / 32; tv.frag_bstride = (long)n * C; tv.c_frag = qk; tv.C = qk;
+    fm = gemm_writes_frag_major(tq) && gemm_writes_frag_major(tv);
+    if (fm) {
+      kfm = pool_.get((size_t)rows * C * es);
+      if (!kfm) return T2P_ERR_HIP;
+      tq.c_frag = kfm;
+      pq = tq;
+      pv = tv;
+    }
+  }
+  T2P_TRY(launch_gemm(pq, s));
+  POOL_GET(vt, void*, (size_t)B * C * npad * es);
   const float att_scale = 1.f / std::sqrt((float)C);
   const float out_alpha = cfg_.skip_rescale ? 0.70710678118654752440f : 1.f;
-  if (g_attn_merged && L.v3.w && attention_strip_eligible(dt, 1, n, n, C, 2 * C, 2 * C, npad, C) && (!x.lowp || olp)) {
+  if (merged) {
     // NIN_2 and NIN_3 as one projection (Layer::v3): the attention kernel's epilogue adds b2 W3 + b3 and the block input and
     // scales by 1 / sqrt 2 -- (x + NIN_3(softmax(q k^T) v)) / sqrt 2, layers.py:170-176 -- no output-projection GEMM
-    DevLinear nob = L.v3;
-    nob.b = nullptr;
-    T2P_TRY(project_vt(dt, nob, a, C, B, n, npad, vt, s));
+    if (fm) {
+      pv.C = vt; pv.c_frag = vt;           // every column fragment-major: C itself receives nothing
+      T2P_TRY(launch_gemm(pv, s));
+    } else {
+      DevLinear nob = L.v3;
+      nob.b = nullptr;
+      T2P_TRY(project_vt(dt, nob, a, C, B, n, npad, vt, s));
+    }
     pool_.put(a);
     POOL_GET(y, float*, (size_t)rows * C * (olp ? es : 4));
     float* y_stats = nullptr;
@@ -1114,7 +1145,10 @@ int Engine::attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     StripEpilogue ep;
     ep.bias = L.v3.b; ep.residual = x.p; ep.r_lowp = x.lowp ? 1 : 0; ep.ldr = C; ep.alpha = out_alpha; ep.out_f32 = olp ? 0 : 1;
     ep.col_stats = y_stats;
-    T2P_TRY(launch_attention_strip(dt, qk, 2 * C, qk + (size_t)C * es, 2 * C, vt, npad, y, C, B, n, C, att_scale, s, &ep));
+    ep.frag_major = fm ? 1 : 0;
+    if (fm) T2P_TRY(launch_attention_strip(dt, qk, 2 * C, kfm, C, vt, npad, y, C, B, n, C, att_scale, s, &ep));
+    else T2P_TRY(launch_attention_strip(dt, qk, 2 * C, qk + (size_t)C * es, 2 * C, vt, npad, y, C, B, n, C, att_scale, s, &ep));
+    pool_.put(kfm);
     pool_.put(qk);
     pool_.put(vt);
     *out = Act{y, C, x.H, x.W, y_stats, olp};
@@ -1143,6 +1177,7 @@ bool g_st_tail = true;
 // development key 43: fewest rows for which the block's last chain (with the third product) is taken; without the third product
 // (plan switch 42 off) the chain needs twice as many (measured at cfg5's 4096 rows: +0.02 ms without, -0.06 ms with it)
 int g_st_tail_rows = 4096;
+bool g_attn_fm = true;         // plan switch 45: fragment-major K / V^T for the wide-head attention kernel (where the shapes allow it)
 bool g_st_fuse_512 = false;    // plan switch 44 (read when the engine is built): row chains at C = 512 too
 bool g_st_ffpo = true;         // plan switch 42: the merged ff.net.2 / proj_out product inside the chain after the cross-attention
 bool g_small_conv_fm = true;   // plan switch 41: the small-map convolution kernel reads fragment-major weight copies

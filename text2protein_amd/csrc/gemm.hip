@@ -159,6 +159,24 @@ DmaPlan dma_plan(const GemmParams& p);
 int launch_splitk_reduce(const GemmParams& p, int nsplit, hipStream_t stream);
 template <typename TC, int MODE> int launch_dma_mode(const GemmParams& p, hipStream_t stream);
 
+// true when reg_epilogue covers the launch (else the LDS-staged dma_epilogue runs; both give the same values)
+__host__ __device__ __forceinline__ bool reg_epilogue_ok(const GemmParams& p, const int nsplit, const int dbg) {
+  if (dbg & 4096) return false;
+  const long c_cols = p.geglu ? p.N / 2 : p.N;
+  const long c_bytes = nsplit > 1 ? (long)p.M * p.N * 4 : ((long)(p.M - 1) * p.ldc + c_cols) * (p.c_f32 ? 4 : 2);
+  const int HW = p.H * p.W;
+  const long r_rows = p.r_up ? (long)(p.M / HW) * (p.H >> 1) * (p.W >> 1) : (long)p.M;
+  const long r_bytes = p.R ? ((r_rows - 1) * p.ldr + p.N) * (p.r_lowp ? 2 : 4) : 0;
+  if ((p.N & 7) || c_bytes >= (1L << 31) || r_bytes >= (1L << 31)) return false;
+  if (nsplit > 1) return true;                                   // raw fp32 partial tiles [M][N]
+  if (p.geglu ? (p.ldc & 3) : (p.ldc & 7)) return false;         // 16-byte aligned row segments (8 bytes for GEGLU's half-width rows)
+  if (p.R && (p.ldr & 7)) return false;
+  if (p.bias_bn && ((p.ld_bn & 3) || p.rows_per_batch % 16)) return false;
+  if (p.r_up && (p.W % 16 || p.rows_per_batch != HW)) return false;
+  return true;
+}
+
+
 #if T2P_PART_HOST
 template <typename TC, bool AF32, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
@@ -764,27 +782,10 @@ __device__ __forceinline__ float row16_sum(float x) {
   return x;
 }
 
-// true when reg_epilogue covers the launch (else the LDS-staged dma_epilogue runs; both give the same values)
-__host__ __device__ __forceinline__ bool reg_epilogue_ok(const GemmParams& p, const int nsplit, const int dbg) {
-  if (dbg & 4096) return false;
-  const long c_cols = p.geglu ? p.N / 2 : p.N;
-  const long c_bytes = nsplit > 1 ? (long)p.M * p.N * 4 : ((long)(p.M - 1) * p.ldc + c_cols) * (p.c_f32 ? 4 : 2);
-  const int HW = p.H * p.W;
-  const long r_rows = p.r_up ? (long)(p.M / HW) * (p.H >> 1) * (p.W >> 1) : (long)p.M;
-  const long r_bytes = p.R ? ((r_rows - 1) * p.ldr + p.N) * (p.r_lowp ? 2 : 4) : 0;
-  if ((p.N & 7) || c_bytes >= (1L << 31) || r_bytes >= (1L << 31)) return false;
-  if (nsplit > 1) return true;                                   // raw fp32 partial tiles [M][N]
-  if (p.geglu ? (p.ldc & 3) : (p.ldc & 7)) return false;         // 16-byte aligned row segments (8 bytes for GEGLU's half-width rows)
-  if (p.R && (p.ldr & 7)) return false;
-  if (p.bias_bn && ((p.ld_bn & 3) || p.rows_per_batch % 16)) return false;
-  if (p.r_up && (p.W % 16 || p.rows_per_batch != HW)) return false;
-  return true;
-}
-
 #ifndef T2P_C_AUX
 #define T2P_C_AUX 0          // cache policy of the register epilogue's 16-bit output stores (measurement variants: 2 nt, 16 sc1, 17 sc0 sc1)
 #endif
-template <typename TC, int BM, int BN, int WM, int WN>
+template <typename TC, int BM, int BN, int WM, int WN, bool CFRAG = false>
 __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc16)[8][4], const int m0, const int n0, const int z0,
                                              const int z1, const int nsplit, const int ks, const int dbg) {
   if ((dbg & 1) && acc16[0][0][0] != 123.456f) return;
@@ -951,8 +952,21 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (f32x4_t){w[0], w[1], w[2], w[3]}), rC, off, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (f32x4_t){w[4], w[5], w[6], w[7]}), rC, off == DMA_OOB ? DMA_OOB : off + 16, 0, 0);
       } else {
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){pack2<TC>(w[0], w[1]), pack2<TC>(w[2], w[3]), pack2<TC>(w[4], w[5]), pack2<TC>(w[6], w[7])},
-                                               rC, off, 0, T2P_C_AUX);
+        const u32x4_t packed = {pack2<TC>(w[0], w[1]), pack2<TC>(w[2], w[3]), pack2<TC>(w[4], w[5]), pack2<TC>(w[6], w[7])};
+        if constexpr (CFRAG) {
+          // columns from frag_col0 on: fragment-major (GemmParams::c_frag).  The 16 rows of a tile lie in one sample (rpb % 16 == 0)
+          const int c = col0 + 32 * h - p.frag_col0;              // wave-uniform sign: frag_col0 % 64 == 0
+          if (c >= 0) {
+            const int rt = row_w + 16 * i;
+            const int bz = p.rows_per_batch > 1 ? rt / p.rows_per_batch : z0;
+            const int rl = row - (p.rows_per_batch > 1 ? bz * p.rows_per_batch : 0);
+            const long e = (long)bz * p.frag_bstride + ((long)(rl >> 5) * p.frag_ns + (c >> 5)) * 1024 + ((c >> 3) & 1) * 512 + ((c >> 4) & 1) * 256 +
+                           (rl & 31) * 8;
+            if ((h ? ok1 : ok0) && rok) *(u32x4_t*)((TC*)p.c_frag + e) = packed;
+            continue;
+          }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(packed, rC, off, 0, T2P_C_AUX);
       }
     }
   };
@@ -1012,8 +1026,8 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
 
 // MF16: use v_mfma_f32_16x16x32 (sustains a higher clock than 32x32x16 at equal cycles per FLOP in
 // LDS-fed loops, MI355X_MICROARCH.md "DVFS give-back" item 7) -- 128 x 64 wave tiles only.
-template <typename TC, int BM, int BN, int WM, int WN, int MODE, int NST, int NSTB = NST, bool MF16 = false, bool REGE = false>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams p, const int tiles_m, const int tiles_n, const int dbg_arg) {
+template <typename TC, int BM, int BN, int WM, int WN, int MODE, int NST, int NSTB, bool MF16, bool REGE, bool CFRAG>
+__device__ __forceinline__ void gemm_dma_body(const GemmParams& p, const int tiles_m, const int tiles_n, const int dbg_arg) {
   // dbg: timing-only ablation mask.  Bits 128 / 256 change the DMA issue order only (results unchanged); every
   // other bit skips work and gives wrong results: those exist in -DT2P_ABLATION builds only (never shipped).
 #ifdef T2P_ABLATION
@@ -1451,8 +1465,17 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams
   }
 
   // REGE (16x16x32 kernels; chosen by the launcher with reg_epilogue_ok): epilogue straight from the registers
-  if constexpr (MF16 && REGE) reg_epilogue<TC, BM, BN, WM, WN>(p, acc16, m0, n0, z0, z1, nsplit, ks, dbg);
+  if constexpr (MF16 && REGE) reg_epilogue<TC, BM, BN, WM, WN, CFRAG>(p, acc16, m0, n0, z0, z1, nsplit, ks, dbg);
   else dma_epilogue<TC, BM, BN, WM, WN, MF16, TI, TJ>(p, smem, acc, acc16, m0, n0, z0, z1, nsplit, ks, dbg);
+}
+template <typename TC, int BM, int BN, int WM, int WN, int MODE, int NST, int NSTB = NST, bool MF16 = false, bool REGE = false>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_dma_kernel(const GemmParams p, const int tiles_m, const int tiles_n, const int dbg_arg) {
+  gemm_dma_body<TC, BM, BN, WM, WN, MODE, NST, NSTB, MF16, REGE, false>(p, tiles_m, tiles_n, dbg_arg);
+}
+// the same kernel writing part of its output fragment-major (GemmParams::c_frag; register epilogue only)
+template <typename TC, int BM, int BN, int WM, int WN, int MODE, int NST, int NSTB>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_dma_cfrag_kernel(const GemmParams p, const int tiles_m, const int tiles_n, const int dbg_arg) {
+  gemm_dma_body<TC, BM, BN, WM, WN, MODE, NST, NSTB, true, true, true>(p, tiles_m, tiles_n, dbg_arg);
 }
 
 // =================================================================================================
@@ -2217,17 +2240,30 @@ bool gemm_fuses_col_stats(const GemmParams& p) {
   return p.M % 64 == 0;
 }
 
+// GemmParams::c_frag: a plain product on the 256 x 256 register-epilogue kernel, 16-bit output, whole 32-row x 32-column fragments
+bool gemm_writes_frag_major(const GemmParams& p) {
+  if (!dma_eligible(p) || p.taps != 1 || p.c_f32 || p.geglu || p.col_stats || p.gn_out || p.r_up || p.c_nchw) return false;
+  if (g_dma_ring != 2 || g_dma_geom != 0) return false;
+  const DmaPlan plan = dma_plan(p);
+  if (plan.geom != 1 || plan.nsplit != 1 || !reg_epilogue_ok(p, 1, 0)) return false;
+  if (p.frag_col0 < 0 || p.frag_col0 % 64 != 0 || (p.N - p.frag_col0) % 32 != 0 || p.frag_ns != (p.N - p.frag_col0) / 32) return false;
+  if (p.rows_per_batch > 1 ? (p.rows_per_batch % 32 != 0 || p.M % p.rows_per_batch != 0 || p.nz0 * p.nz1 != 1) : (p.M % 32 != 0 || p.nz1 != 1)) return false;
+  return true;
+}
+
 #endif  // T2P_PART_HOST
 
 #if T2P_PART_DMA
-template <typename TC, int MODE, int BM, int BN, int WM, int WN, int NST, int NSTB = NST, bool MF16 = false, bool REGE = false>
+template <typename TC, int MODE, int BM, int BN, int WM, int WN, int NST, int NSTB = NST, bool MF16 = false, bool REGE = false, bool CF = false>
 static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
   constexpr int smem = NST * BM * 128 + NSTB * BN * 128;
   constexpr int threads = WM * WN * 64;
   if constexpr (MF16 && !REGE && MODE != 3) {          // the register epilogue wherever it covers the launch
     if (reg_epilogue_ok(p, dma_plan(p).nsplit, g_dbg)) return launch_dma_geom<TC, MODE, BM, BN, WM, WN, NST, NSTB, true, true>(p, stream);
   }
-  auto kern = gemm_dma_kernel<TC, BM, BN, WM, WN, MODE, NST, NSTB, MF16, REGE>;
+  void (*kern)(const GemmParams, const int, const int, const int);
+  if constexpr (CF) kern = gemm_dma_cfrag_kernel<TC, BM, BN, WM, WN, MODE, NST, NSTB>;     // part of the output fragment-major (GemmParams::c_frag)
+  else kern = gemm_dma_kernel<TC, BM, BN, WM, WN, MODE, NST, NSTB, MF16, REGE>;
   T2P_TRY(ensure_dynamic_lds((const void*)kern, smem));
   const int Mq = MODE == 3 ? p.M / 4 : p.M;               // MODE 3: one output phase per launch
   const int tiles_m = (Mq + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -2241,7 +2277,7 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
     rec.flops = MODE == 3 ? 2.0 * Mq * p.N * 4.0 * (p.C0 + p.C1) * (p.up_phase == 5 ? 4 : 1)     // the multiplications this launch executes
                           : 2.0 * p.M * p.N * ((double)p.taps * (p.C0 + p.C1) + p.CX0 + p.CX1) * p.nz0 * p.nz1;
     rec.kind = p.taps == 9 ? 0 : 1;
-    static const std::string kname = std::string("gemm_dma_kernel<") + (dtype_of<TC>::value == DT_F16 ? "f16_t" : "bf16_t") + ", " +
+    static const std::string kname = std::string(CF ? "gemm_dma_cfrag_kernel<" : "gemm_dma_kernel<") + (dtype_of<TC>::value == DT_F16 ? "f16_t" : "bf16_t") + ", " +
                                      std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) +
                                      ", " + std::to_string(MODE) + ", " + std::to_string(NST) + ", " + std::to_string(NSTB) + ", " +
                                      (MF16 ? "true" : "false") + ", " + (REGE ? "true" : "false") + ">";
@@ -2325,6 +2361,12 @@ static bool up4_eligible(const GemmParams& p, const DmaPlan& plan) {
 template <typename TC, int MODE>
 int launch_dma_mode(const GemmParams& p, hipStream_t stream) {
   const DmaPlan plan = dma_plan(p);
+  if constexpr (MODE == 0) {
+    if (p.c_frag) {
+      T2P_REQUIRE(gemm_writes_frag_major(p), "this product does not take the fragment-major output (ask gemm_writes_frag_major)");
+      return launch_dma_geom<TC, 0, 256, 256, 2, 4, 2, 2, true, true, true>(p, stream);
+    }
+  }
   if constexpr (MODE == 2) {
     if (up4_eligible(p, plan)) {
       GemmParams q = p;

@@ -155,7 +155,16 @@ struct GemmParams {
   const float* an_gamma = nullptr;
   const float* an_beta = nullptr;
   int an_groups = 0, an_silu = 0;
+  // optional (ask gemm_writes_frag_major): the columns from frag_col0 on are written FRAGMENT-MAJOR into c_frag (16-bit) instead
+  // of row-major into C -- the layout the wide-head attention kernel streams K and V^T from with whole cache lines per load
+  // (attention.hip): element (r, c) of sample / batch entry bz, c relative to frag_col0, at
+  //   bz frag_bstride + ((r / 32) frag_ns + c / 32) 1024 + ((c / 8) % 2) 512 + ((c / 16) % 2) 256 + (r % 32) 8 + c % 8
+  // with r the row inside the sample (rows_per_batch rows each, bz = row / rows_per_batch) or inside batch entry z (bz = z)
+  void* c_frag = nullptr;
+  int frag_col0 = 0, frag_ns = 0;
+  long frag_bstride = 0;
 };
+bool gemm_writes_frag_major(const GemmParams& p);
 
 int launch_gemm(const GemmParams& p, hipStream_t stream);
 bool gemm_fuses_col_stats(const GemmParams& p);

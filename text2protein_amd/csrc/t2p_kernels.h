@@ -141,7 +141,9 @@ struct StripEpilogue {
   float alpha = 1.f;
   int out_f32 = 0;
   float* col_stats = nullptr;
+  int frag_major = 0;      // k and vt are fragment-major [B][n d] (GemmParams::c_frag of their projections; attention_strip_frag_major_ok)
 };
+bool attention_strip_frag_major_ok(int dtype, int n, int d);
 int launch_attention_strip(int dtype, const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
                            int B, int n, int d, float scale, hipStream_t s, const StripEpilogue* ep = nullptr);
 
@@ -197,6 +199,7 @@ struct StEntryArgs {
 };
 extern bool g_st_fuse;
 extern bool g_small_conv_fm;   // engine.cpp (plan switch 41)
+extern bool g_attn_fm;         // engine.cpp (plan switch 45)
 extern bool g_st_fuse_512;     // engine.cpp (plan switch 44, read at engine build)
 extern int g_st_tail_rows;     // engine.cpp (development key 43)
 extern bool g_st_ffpo;         // engine.cpp (plan switch 42)
