@@ -532,7 +532,7 @@ def test_input_conv_and_its_column_statistics(lib, C, nf, H, W):
 
 @pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("B,n,mode", [(3, 256, "entry"), (2, 64, "entry"), (5, 32, "normed"), (32, 256, "entry"), (1, 1024, "normed"),
-                                      (3, 256, "mid"), (32, 256, "mid"), (4, 64, "mid"), (3, 256, "tail"), (32, 256, "tail"),
+                                      (3, 256, "mid"), (32, 256, "mid"), (4, 64, "mid"), (32, 16, "mid"), (32, 16, "normed"), (3, 256, "tail"), (32, 256, "tail"),
                                       (3, 256, "tail3"), (32, 256, "tail3"), (6, 64, "tail3"),
                                       (3, 256, "entry512"), (32, 256, "entry512"), (5, 32, "normed512"), (8, 64, "mid512"), (32, 256, "mid512")])
 def test_spatial_transformer_row_chain(lib, dt, B, n, mode):
@@ -605,9 +605,12 @@ def test_spatial_transformer_row_chain(lib, dt, B, n, mode):
     else:
         assert rel_l2(out2.float().cpu(), out2_ref) < 2 * tol
     # refused, not silently computed by something else: other channel counts, ragged row blocks
-    if csp is None and C == 256:
+    if C == 256:
         assert lib.t2p_op_st_entry(*args(128, n)) != 0
-        assert lib.t2p_op_st_entry(*args(C, 48)) != 0
+        if csp is not None or tail3:
+            assert lib.t2p_op_st_entry(*args(C, 48)) != 0         # per-sample statistics need whole 32- / 64-row blocks per sample
+        elif (B * 40) % 32 != 0:
+            assert lib.t2p_op_st_entry(*args(C, 40)) != 0         # (without them any split of the rows will do: B n % 32 == 0)
 
 
 def _frag_major(x):

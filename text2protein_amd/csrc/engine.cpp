@@ -1209,7 +1209,17 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
     e.w_in = L.fm_in; e.b_in = L.proj_in.b;
     e.ln_gamma = L.ln1.gamma; e.ln_beta = L.ln1.beta; e.ln_eps = 1e-5f;
     e.w_qkv = L.fm_qkv; e.n2 = 3 * C;
-    if ((normed || x.cstats) && L.proj_in.b && L.fm_in && st_entry_eligible(e)) {
+    // (no column sums and no producer-side norm -- the 4 x 4 level: the GroupNorm as its own small launch, the rest of the chain here)
+    void* a_small = nullptr;
+    if (!normed && !x.cstats && L.proj_in.b && L.fm_in && g_st_fuse) {
+      StEntryArgs probe = e;
+      probe.x = x.p; probe.cstats = nullptr;
+      if (st_entry_eligible(probe)) {
+        T2P_TRY(group_norm(x, nullptr, L.gn0, 1e-6f, 0, 0, B, &a_small, s));
+        e.x = a_small; e.cstats = nullptr;
+      }
+    }
+    if ((normed || x.cstats || a_small) && L.proj_in.b && L.fm_in && st_entry_eligible(e)) {
       qkv_pre = (char*)pool_.get((size_t)rows * 3 * C * es);
       if (!qkv_pre) return T2P_ERR_HIP;
       if (mega) {
@@ -1225,6 +1235,7 @@ int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
       T2P_TRY(launch_st_entry(e, s));
       if (normed) { pool_.put(x.pre_norm); x.pre_norm = nullptr; }
     }
+    pool_.put(a_small);
   }
   if (!qkv_pre) {
     void* a = nullptr;

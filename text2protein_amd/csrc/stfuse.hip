@@ -443,7 +443,10 @@ bool g_st_fuse = true;      // plan switch 39
 bool st_entry_eligible(const StEntryArgs& a) {
   if (!g_st_fuse || (a.dtype != DT_F16 && a.dtype != DT_BF16) || (a.C != 256 && a.C != 512)) return false;
   if (a.C == 512 && (a.geglu || a.w3)) return false;          // (the feed-forward chains stream 4x the bytes there: not built)
-  if (a.n % SF_ROWS != 0 || (long)a.B * a.n > 8192) return false;      // one round of workgroups (two rounds measured slower: cfg4's 32x32 level)
+  // one round of workgroups (two rounds measured slower: cfg4's 32x32 level); a workgroup's 32 rows lie in one sample, except when
+  // nothing per-sample is involved (no GroupNorm inside, no column sums out): then any split of the rows will do (4 x 4 maps)
+  const bool per_sample = a.cstats || a.y_stats;
+  if ((long)a.B * a.n > 8192 || ((long)a.B * a.n) % SF_ROWS != 0 || (per_sample && a.n % SF_ROWS != 0)) return false;
   if (a.geglu ? a.n2 != 8 * a.C : (a.n2 != a.C && a.n2 != 3 * a.C)) return false;
   if (a.w3 && (!a.geglu || !a.b3 || !a.res3 || !a.y || (a.y_stats && a.n % 64 != 0))) return false;
   if (a.cstats && (a.n % 64 != 0 || a.groups <= 0 || a.C % a.groups != 0)) return false;
