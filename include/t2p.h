@@ -203,6 +203,13 @@ int t2p_op_st_entry(int dtype, const void* x, const float* col_stats, int groups
                     const float* ln_beta, float ln_eps, const void* w_2, int n2, const float* b_2, int geglu, void* t, void* out2,
                     const void* w_3, const float* b_3, const void* res3, void* y, float* y_stats, int batch, int n, int C,
                     void* stream);
+/* the projections of an AttnBlockpp (layers.py:160-167) in ONE launch over 32-row blocks at C = 256: h = GroupNorm(x) (statistics from
+ * col_stats as in t2p_op_st_entry, or x already normalised), qk [batch n][2 C] = h [W_0 | W_1]^T + b (NIN_0 | NIN_1), and
+ * vt [batch][C][npad] = (h W_v^T)^T: the value projection written transposed (the engine passes NIN_2 . NIN_3 as W_v).
+ * x, w_qk [2 C][C], w_v [C][C], qk, vt in the 16-bit compute dtype.  n % 32 == 0, batch n <= 8192, npad >= n, npad % 4 == 0 */
+int t2p_op_attn_proj(int dtype, const void* x, const float* col_stats, int groups, const float* gn_gamma, const float* gn_beta,
+                     float gn_eps, const void* w_qk, const float* b_qk, const void* w_v, void* qk, void* vt, int64_t npad,
+                     int batch, int n, int C, void* stream);
 /* the network's input convolution (pre_conv, ncsnpp.py:230: 3x3, C = 5 or 8 input channels -> nf) straight from the NCHW fp32
  * sample, in fp32 arithmetic: x [batch][C][H][W] fp32; w_tcn [3*3][C][nf] fp32 (tap-major); out NHWC [batch][H][W][nf] in
  * out_dtype.  col_stats (optional; W % 64 == 0, nf | 256): [batch H W / 64][nf][2] fp32 = (sum, sum of squares) of the fp32

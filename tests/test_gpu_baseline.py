@@ -512,3 +512,36 @@ def test_fragment_major_attention_operands_match_row_major(stem):
     _record(f"attn_frag_major_{stem}", {"row_major_vs_reference": e[0], "frag_major_vs_reference": e[1], "identical": bool(torch.equal(outs[0], outs[1]))})
     assert torch.equal(outs[0], outs[1])
     assert e[1] < F16_SCORE_TOL
+
+
+@pytest.mark.parametrize("stem", ["cond_length", "cond_length_inpainting"])
+def test_attention_block_projections_in_one_launch_match(stem):
+    """Plan switch 46: GroupNorm apply, q | k and the transposed value projection of every AttnBlockpp of the C = 256 configurations as one
+    launch over 32-row blocks (attn_proj_kernel).  Both plans against the reference's full-size scores at the benchmark batch."""
+    from text2protein_amd import _lib, synth
+    cfg, B0, T, chains = _cfg(stem)
+    g = load_golden("full_" + stem)
+    sd = synth.synth_state_dict(cfg, 0)
+    x, labels, ctx = full_inputs(cfg, B0, T)
+    xs = torch.from_numpy(synth.normal(79, "filler_x", chains * x[0].numel()).reshape(chains, *x.shape[1:])).cuda() * 20.0
+    cs = synth.synth_context(chains, T, cfg.model.context_dim, 80).cuda()
+    ls = (torch.arange(chains, device="cuda") * 29 + 5) % cfg.model.num_scales
+    for i, s in enumerate((3, chains - 2)):
+        xs[s], cs[s], ls[s] = x[i].cuda(), ctx[i].cuda(), labels[i].cuda()
+    lib = _lib.load()
+    m16 = _model(cfg, sd, "f16")
+    outs = {}
+    try:
+        for sw in (0, 1):
+            _lib.check(lib.t2p_debug_set(46, sw))
+            outs[sw] = m16(xs, ls, cs).cpu()
+            assert torch.equal(outs[sw], m16(xs, ls, cs).cpu())
+    finally:
+        lib.t2p_debug_set(46, 1)
+    # (the same products accumulated in the same order: the scores come out bit-identical -- that the kernel runs is visible in the
+    # dispatch count, 10 fewer per PC step: profiles/README.md)
+    d = rel_l2(outs[1], outs[0])
+    e = {sw: max(rel_l2(outs[sw][s], g["score"][i]) for i, s in enumerate((3, chains - 2))) for sw in (0, 1)}
+    print(f"{stem}: AttnBlockpp projections in one launch vs separate: rel-L2 = {d:.3e}; vs reference: separate {e[0]:.3e}, one launch {e[1]:.3e}")
+    _record(f"attn_proj_{stem}", {"fused_vs_separate": d, "separate_vs_reference": e[0], "fused_vs_reference": e[1]})
+    assert d < F16_SCORE_TOL and e[1] < F16_SCORE_TOL and e[1] < 1.05 * e[0]

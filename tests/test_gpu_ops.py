@@ -613,6 +613,42 @@ def test_spatial_transformer_row_chain(lib, dt, B, n, mode):
             assert lib.t2p_op_st_entry(*args(C, 40)) != 0         # (without them any split of the rows will do: B n % 32 == 0)
 
 
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("B,n,with_stats", [(3, 256, True), (32, 256, True), (2, 64, False), (5, 32, False)])
+def test_attention_block_projections_in_one_launch(lib, dt, B, n, with_stats):
+    """t2p_op_attn_proj: GroupNorm -> q | k (+ bias) and the value projection written transposed, one launch over 32-row blocks
+    (AttnBlockpp, layers.py:160-167), against fp64 with the roundings of the separate launches."""
+    Cc, G = 256, 32
+    td = TDT[dt]
+    g = torch.Generator().manual_seed(7 * n + B)
+    x = (torch.randn(B, n, Cc, generator=g) * 1.5 + 0.3 * torch.randn(B, 1, Cc, generator=g)).to(td)
+    gamma, beta = 1 + 0.2 * torch.randn(Cc, generator=g), 0.2 * torch.randn(Cc, generator=g)
+    w_qk = (torch.randn(2 * Cc, Cc, generator=g) / Cc ** 0.5).to(td)
+    b_qk = 0.3 * torch.randn(2 * Cc, generator=g)
+    w_v = (torch.randn(Cc, Cc, generator=g) / Cc ** 0.5).to(td)
+    csp = None
+    if with_stats:
+        xg = x.double().reshape(B, n, G, Cc // G)
+        mean, var = xg.mean(dim=(1, 3), keepdim=True), xg.var(dim=(1, 3), unbiased=False, keepdim=True)
+        a = (((xg - mean) / torch.sqrt(var + 1e-6)).reshape(B, n, Cc) * gamma.double() + beta.double()).to(td)
+        chunks = x.float().reshape(B * n // 64, 64, Cc)
+        csp = P(dev(torch.stack([chunks.sum(1), (chunks ** 2).sum(1)], dim=-1).contiguous()))
+    else:
+        a = x
+    qk_ref = a.double() @ w_qk.double().T + b_qk.double()
+    vt_ref = (a.double() @ w_v.double().T).transpose(1, 2)                      # [B][C][n]
+    npad = n + 8
+    qk = torch.full((B, n, 2 * Cc), float("nan"), device="cuda", dtype=td)
+    vt = torch.full((B, Cc, npad), float("nan"), device="cuda", dtype=td)
+    check(lib, lib.t2p_op_attn_proj(dt, P(dev(x)), csp, G, P(dev(gamma)), P(dev(beta)), 1e-6, P(dev(w_qk)), P(dev(b_qk)), P(dev(w_v)), P(qk), P(vt),
+                                    npad, B, n, Cc, None))
+    torch.cuda.synchronize()
+    tol = 1.5e-3 if dt == 2 else 1.2e-2
+    assert rel_l2(qk.float().cpu(), qk_ref) < tol
+    assert rel_l2(vt[..., :n].float().cpu(), vt_ref) < tol
+    assert torch.isnan(vt[..., n:].float()).all()                              # the padding columns are not touched
+
+
 def _frag_major(x):
     """[..., R, Ccols] -> the fragment-major order of GemmParams::c_frag (flattened last two dimensions)."""
     R, Cc = x.shape[-2:]

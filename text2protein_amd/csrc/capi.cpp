@@ -307,6 +307,26 @@ int t2p_op_st_entry(int dtype, const void* x, const float* col_stats, int groups
   API_END
 }
 
+int t2p_op_attn_proj(int dtype, const void* x, const float* col_stats, int groups, const float* gn_gamma, const float* gn_beta, float gn_eps,
+                     const void* w_qk, const float* b_qk, const void* w_v, void* qk, void* vt, int64_t npad, int batch, int n, int C, void* stream) {
+  API_BEGIN
+  AttnProjArgs e;
+  e.dtype = dtype; e.B = batch; e.n = n; e.C = C; e.npad = npad; e.x = x; e.cstats = col_stats; e.groups = groups; e.gn_gamma = gn_gamma;
+  e.gn_beta = gn_beta; e.gn_eps = gn_eps; e.b_qk = b_qk; e.qk = qk; e.vt = vt;
+  T2P_REQUIRE(attn_proj_eligible(e), "attn_proj: C = 256, 16-bit dtype, n % 32 == 0 (64 with column sums), batch n <= 8192, npad % 4 == 0");
+  void* fm = nullptr;
+  T2P_HIP_CHECK(hipMalloc(&fm, (size_t)3 * C * C * 2));
+  void* fm2 = (char*)fm + (size_t)2 * C * C * 2;
+  int rc = launch_sf_frag_major(dtype, w_qk, fm, 2 * C, C, (hipStream_t)stream);
+  if (rc == T2P_OK) rc = launch_sf_frag_major(dtype, w_v, fm2, C, C, (hipStream_t)stream);
+  e.w_qk = fm; e.w_v = fm2;
+  if (rc == T2P_OK) rc = launch_attn_proj(e, (hipStream_t)stream);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(fm);
+  return rc;
+  API_END
+}
+
 int t2p_op_input_conv(const float* x, const float* w_tcn, const float* bias, void* out, int out_dtype, int batch, int C, int H, int W,
                       int nf, float* col_stats, void* stream) {
   API_BEGIN
@@ -578,6 +598,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 43) { t2p::g_st_tail_rows = value; return T2P_OK; }
   if (key == 44) { t2p::g_st_fuse_512 = value != 0; return T2P_OK; }
   if (key == 45) { t2p::g_attn_fm = value != 0; return T2P_OK; }
+  if (key == 46) { t2p::g_attn_proj = value != 0; return T2P_OK; }
   if (key == 34) { set_gemm_a_norm(value != 0); return T2P_OK; }
   if (key == 32) { g_attn_merged = value != 0; return T2P_OK; }
   if (key == 33) { g_ffpo_merged = value != 0; return T2P_OK; }

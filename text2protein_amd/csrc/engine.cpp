@@ -569,6 +569,14 @@ int Engine::finalize() {
         T2P_TRY(upload_matrix(pool_, to_nk(m, false, true), cfg_.compute_dtype, &l.v3.w));
         T2P_TRY(upload_f32(bb, &l.v3.b));
         l.v3.N = ci; l.v3.K = ci;
+        if (ci == 256 && l.qk.w && l.qk.b) {
+          l.fm_qk = pool_.persistent((size_t)2 * ci * ci * 2);
+          l.fm_v3 = pool_.persistent((size_t)ci * ci * 2);
+          if (!l.fm_qk || !l.fm_v3) return T2P_ERR_HIP;
+          T2P_TRY(launch_sf_frag_major(cfg_.compute_dtype, l.qk.w, l.fm_qk, 2 * ci, ci, nullptr));
+          T2P_TRY(launch_sf_frag_major(cfg_.compute_dtype, l.v3.w, l.fm_v3, ci, ci, nullptr));
+          T2P_HIP_CHECK(hipStreamSynchronize(nullptr));
+        }
       }
     } else {
       const std::string t = p + ".transformer_blocks.0";
@@ -1090,11 +1098,43 @@ int Engine::attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
   const int C = x.C, n = x.H * x.W, dt = dtype();
   const size_t es = dtype_size(dt);
   const long rows = (long)B * n, npad = (long)round_up((size_t)n, 8);
+  const bool olp = res_lowp();
+  const bool merged = g_attn_merged && L.v3.w && attention_strip_eligible(dt, 1, n, n, C, 2 * C, 2 * C, npad, C) && (!x.lowp || olp);
+  if (merged && x.lowp && L.fm_qk && g_attn_proj) {
+    // C = 256: GroupNorm apply, q | k and the transposed value projection as ONE launch over 32-row blocks (attn_proj_kernel)
+    AttnProjArgs e;
+    e.dtype = dt; e.B = B; e.n = n; e.C = C; e.npad = npad;
+    const bool normed = x.pre_norm && x.pre_for == &L.gn0 && x.pre_silu == 0;
+    e.x = normed ? x.pre_norm : (const void*)x.p;
+    e.cstats = normed ? nullptr : x.cstats;
+    e.gn_gamma = L.gn0.gamma; e.gn_beta = L.gn0.beta; e.groups = L.gn0.G; e.gn_eps = 1e-6f;
+    e.w_qk = L.fm_qk; e.b_qk = L.qk.b; e.w_v = L.fm_v3;
+    if ((normed || x.cstats) && attn_proj_eligible(e)) {
+      POOL_GET(qk2, char*, (size_t)rows * 2 * C * es);
+      POOL_GET(vt2, void*, (size_t)B * C * npad * es);
+      e.qk = qk2; e.vt = vt2;
+      T2P_TRY(launch_attn_proj(e, s));
+      if (normed) { pool_.put(x.pre_norm); x.pre_norm = nullptr; }
+      const float att_scale2 = 1.f / std::sqrt((float)C);
+      POOL_GET(y, float*, (size_t)rows * C * (olp ? es : 4));
+      float* y_stats = nullptr;
+      if (g_fuse_gn_stats && n % 64 == 0) {
+        y_stats = (float*)pool_.get((size_t)(rows / 64) * C * 2 * 4);
+        if (!y_stats) return T2P_ERR_HIP;
+      }
+      StripEpilogue ep;
+      ep.bias = L.v3.b; ep.residual = x.p; ep.r_lowp = 1; ep.ldr = C; ep.alpha = cfg_.skip_rescale ? 0.70710678118654752440f : 1.f;
+      ep.out_f32 = olp ? 0 : 1; ep.col_stats = y_stats;
+      T2P_TRY(launch_attention_strip(dt, qk2, 2 * C, qk2 + (size_t)C * es, 2 * C, vt2, npad, y, C, B, n, C, att_scale2, s, &ep));
+      pool_.put(qk2);
+      pool_.put(vt2);
+      *out = Act{y, C, x.H, x.W, y_stats, olp};
+      return T2P_OK;
+    }
+  }
   void* a = nullptr;
   T2P_TRY(group_norm(x, nullptr, L.gn0, 1e-6f, 0, 0, B, &a, s));
   POOL_GET(qk, char*, (size_t)rows * 2 * C * es);
-  const bool olp = res_lowp();
-  const bool merged = g_attn_merged && L.v3.w && attention_strip_eligible(dt, 1, n, n, C, 2 * C, 2 * C, npad, C) && (!x.lowp || olp);
   // q | k projection; where the wide-head attention kernel takes fragment-major operands (plan switch 45: the 32 x 32 level of the
   // C = 512 configurations) the k columns and the transposed values are written that way by the products' epilogues
   GemmParams pq;
@@ -1177,6 +1217,7 @@ bool g_st_tail = true;
 // development key 43: fewest rows for which the block's last chain (with the third product) is taken; without the third product
 // (plan switch 42 off) the chain needs twice as many (measured at cfg5's 4096 rows: +0.02 ms without, -0.06 ms with it)
 int g_st_tail_rows = 4096;
+bool g_attn_proj = true;       // plan switch 46: the projections of an AttnBlockpp in one launch at C = 256 (attn_proj_kernel)
 bool g_attn_fm = true;         // plan switch 45: fragment-major K / V^T for the wide-head attention kernel (where the shapes allow it)
 bool g_st_fuse_512 = false;    // plan switch 44 (read when the engine is built): row chains at C = 512 too
 bool g_st_ffpo = true;         // plan switch 42: the merged ff.net.2 / proj_out product inside the chain after the cross-attention

@@ -68,6 +68,7 @@ struct Layer {
   // 16-bit modes: NIN_2 and NIN_3 as one matrix -- rows of softmax(..) sum to 1, so NIN_3(P (h W2 + b2)) = P (h W2 W3) + (b2 W3 + b3):
   // v3 = (W2 W3)^T [C][C] feeds the transposed value projection, v3.b = b2 W3 + b3 is added by the attention kernel's epilogue
   DevLinear v3;
+  void* fm_qk = nullptr; void* fm_v3 = nullptr;   // C = 256: fragment-major copies of qk and v3 for attn_proj_kernel (stfuse.hip)
   // st (SpatialTransformer)
   DevLinear a1_qkv;   // 16-bit modes: to_q | to_k | to_v stacked, one projection GEMM for the self-attention
   DevLinear proj_in, proj_out, a1_qk, a1_v, a1_out, a2_q, a2_k, a2_v, a2_out, ff1, ff2;

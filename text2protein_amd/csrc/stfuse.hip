@@ -93,7 +93,9 @@ int launch_sf_frag_major(int dtype, const void* W, void* out, int N, int K, hipS
 // 16 rt + (lane & 15), column 16 ct + 4 (lane >> 4) + e.  The weight fragments of a column tile are one L2 round trip away and
 // its matrix work is 16 MFMAs: DEPTH tiles are kept in flight (`ring`, filled by sf_prefetch ahead of the stage: a one-tile
 // look-ahead left the q | k | v stage waiting for every tile: 25.6 us for the whole chain).
-template <typename TC, int K, int RS, int TPW, int DEPTH, typename Epi>
+// SWAP: the activations first -- a lane then ends with 4 consecutive ROWS of one column (acc[rt][e] = row 16 rt + 4 (lane >> 4) + e,
+// column 16 ct + (lane & 15)): the orientation of a transposed store
+template <typename TC, int K, int RS, int TPW, int DEPTH, bool SWAP = false, typename Epi>
 __device__ __forceinline__ void sf_stage(const unsigned char* a_lds, const TC* W, const float* bias, const int wave, const int lane,
                                          sf_u32x4 (&ring)[DEPTH][K / 32], float4 (&bring)[DEPTH], Epi&& epi) {
   constexpr int NS = K / 32;
@@ -114,8 +116,13 @@ __device__ __forceinline__ void sf_stage(const unsigned char* a_lds, const TC* W
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       if constexpr (CACHE) {
-        SfMma<TC>::run(ring[i % DEPTH][s], af[0][s], acc[0]);
-        SfMma<TC>::run(ring[i % DEPTH][s], af[1][s], acc[1]);
+        if constexpr (SWAP) {
+          SfMma<TC>::run(af[0][s], ring[i % DEPTH][s], acc[0]);
+          SfMma<TC>::run(af[1][s], ring[i % DEPTH][s], acc[1]);
+        } else {
+          SfMma<TC>::run(ring[i % DEPTH][s], af[0][s], acc[0]);
+          SfMma<TC>::run(ring[i % DEPTH][s], af[1][s], acc[1]);
+        }
       } else {
         const sf_u32x4 a0 = *(const sf_u32x4*)(ar + 64 * s), a1 = *(const sf_u32x4*)(ar + 16 * RS + 64 * s);
         SfMma<TC>::run(ring[i % DEPTH][s], a0, acc[0]);
@@ -437,6 +444,121 @@ __global__ __launch_bounds__(512) void st_entry_kernel(const StEntryArgs a) {
   }
   SF_STAMP(6)
   SF_STAMPS_OUT(a.qkv)
+}
+
+// ---- the projections of an AttnBlockpp in one launch (C = 256): h = GroupNorm(x) -> q | k = NIN_0 | NIN_1 (h) row-major, and
+// V^T = (NIN_2 . NIN_3)(h)^T, written transposed straight from the accumulators (layers.py:160-167; the engine's merged value projection).
+// Replaces the GroupNorm apply (when the producer did not already apply it), the q | k GEMM and the batched transposed projection.
+template <typename TC, int C>
+__global__ __launch_bounds__(512) void attn_proj_kernel(const AttnProjArgs a) {
+  constexpr int RS = C * 2 + 16, NS = C / 32, DEPTH = 3;
+  __shared__ __attribute__((aligned(16))) unsigned char bufx[SF_ROWS * RS];
+  __shared__ double dred[2][C];
+  __shared__ float gsc[C], gsh[C];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, g4 = lane >> 4;
+  const int m0 = blockIdx.x * SF_ROWS;
+  const int b = m0 / a.n;
+  sf_u32x4 ring[DEPTH][NS];
+  float4 bring[DEPTH];
+  sf_prefetch<TC, C, 2 * C / 128, DEPTH>((const TC*)a.w_qk, a.b_qk, wave, lane, ring, bring);
+  constexpr int XPT = SF_ROWS * (C / 8) / 512;
+  sf_u32x4 xr[XPT];
+  {
+    const TC* X = (const TC*)a.x + (long)m0 * C;
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) {
+      const int i = tid + 512 * k, r = i / (C / 8), j = i - r * (C / 8);
+      xr[k] = *(const sf_u32x4*)(X + (long)r * C + j * 8);
+    }
+  }
+  if (a.cstats) {              // (st_entry_kernel's fold)
+    const int nchunk = a.n >> 6, cpg = C / a.groups;
+    const int c = tid & (C - 1), part = tid / C;
+    constexpr int PARTS = 512 / C;
+    const float ggam = a.gn_gamma[c], gbet = a.gn_beta[c];
+    double s = 0, q = 0;
+    const float* cs = a.cstats + ((long)b * nchunk * C + c) * 2;
+    for (int ch = part; ch < nchunk; ch += PARTS) {
+      const float2 v = *(const float2*)(cs + (long)ch * C * 2);
+      s += v.x; q += v.y;
+    }
+    if (part > 0) { dred[0][c] = s; dred[1][c] = q; }
+    __syncthreads();
+    if (part == 0 && PARTS > 1) { s += dred[0][c]; q += dred[1][c]; }
+    __syncthreads();
+    if (part == 0) { dred[0][c] = s; dred[1][c] = q; }
+    __syncthreads();
+    if (part == 0) {
+      const int g0 = (c / cpg) * cpg;
+      double gs = 0, gq = 0;
+      for (int k = 0; k < cpg; ++k) { gs += dred[0][g0 + k]; gq += dred[1][g0 + k]; }
+      const double cnt = (double)a.n * cpg, mean = gs / cnt;
+      double var = gq / cnt - mean * mean;
+      if (var < 0) var = 0;
+      const float sc = (float)(1.0 / sqrt(var + (double)a.gn_eps)) * ggam;
+      gsc[c] = sc;
+      gsh[c] = gbet - (float)mean * sc;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < XPT; ++k) {
+    const int i = tid + 512 * k, r = i / (C / 8), j = i - r * (C / 8);
+    sf_u32x4 u = xr[k];
+    if (a.cstats) {
+      unsigned o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = j * 8 + 2 * q;
+        o[q] = sf_pack2<TC>(sf_lo<TC>(u[q]) * gsc[c] + gsh[c], sf_hi<TC>(u[q]) * gsc[c + 1] + gsh[c + 1]);
+      }
+      u = sf_u32x4{o[0], o[1], o[2], o[3]};
+    }
+    *(sf_u32x4*)(bufx + r * RS + j * 16) = u;
+  }
+  __syncthreads();
+  // q | k (+ bias), row-major [rows][2 C]
+  {
+    TC* Q = (TC*)a.qk;
+    sf_stage<TC, C, RS, 2 * C / 128, DEPTH>(bufx, (const TC*)a.w_qk, a.b_qk, wave, lane, ring, bring,
+                                            [&](int i, int ct, sf_f32x4 (&acc)[2], const float4 bb) {
+      const int col = ct * 16 + 4 * g4;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+        *(sf_u32x2*)(Q + (long)(m0 + rt * 16 + l16) * (2 * C) + col) =
+            sf_u32x2{sf_pack2<TC>(acc[rt][0] + bb.x, acc[rt][1] + bb.y), sf_pack2<TC>(acc[rt][2] + bb.z, acc[rt][3] + bb.w)};
+    });
+  }
+  // V^T [B][C][npad]: activations first, so a lane holds 4 consecutive keys of one channel: an 8-byte piece of a V^T row
+  sf_prefetch<TC, C, C / 128, DEPTH>((const TC*)a.w_v, nullptr, wave, lane, ring, bring);
+  {
+    TC* VT = (TC*)a.vt + (long)b * C * a.npad + (m0 - b * a.n);
+    sf_stage<TC, C, RS, C / 128, DEPTH, true>(bufx, (const TC*)a.w_v, nullptr, wave, lane, ring, bring,
+                                              [&](int i, int ct, sf_f32x4 (&acc)[2], const float4) {
+      const int ch = ct * 16 + l16;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+        *(sf_u32x2*)(VT + (long)ch * a.npad + rt * 16 + 4 * g4) =
+            sf_u32x2{sf_pack2<TC>(acc[rt][0], acc[rt][1]), sf_pack2<TC>(acc[rt][2], acc[rt][3])};
+    });
+  }
+}
+
+bool attn_proj_eligible(const AttnProjArgs& a) {
+  if (!g_st_fuse || (a.dtype != DT_F16 && a.dtype != DT_BF16) || a.C != 256) return false;
+  if (a.n % SF_ROWS != 0 || (long)a.B * a.n > 8192 || a.npad % 4 != 0 || a.npad < a.n) return false;
+  if (a.cstats && (a.n % 64 != 0 || a.groups <= 0 || a.C % a.groups != 0)) return false;
+  return true;
+}
+int launch_attn_proj(const AttnProjArgs& a, hipStream_t s) {
+  T2P_REQUIRE(attn_proj_eligible(a) && a.x && a.w_qk && a.b_qk && a.w_v && a.qk && a.vt, "attn_proj arguments");
+  T2P_REQUIRE(!a.cstats || (a.gn_gamma && a.gn_beta), "attn_proj: GroupNorm parameters");
+  const dim3 grid((unsigned)((long)a.B * a.n / SF_ROWS));
+  if (a.dtype == DT_F16) hipLaunchKernelGGL((attn_proj_kernel<f16_t, 256>), grid, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((attn_proj_kernel<bf16_t, 256>), grid, dim3(512), 0, s, a);
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
 }
 
 bool g_st_fuse = true;      // plan switch 39

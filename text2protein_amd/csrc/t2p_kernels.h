@@ -197,8 +197,23 @@ struct StEntryArgs {
   void* t = nullptr;                     // out [B n][C] 16-bit: the block's residual stream
   void* qkv = nullptr;                   // out [B n][n2] 16-bit
 };
+// the projections of an AttnBlockpp in one launch (C = 256): GroupNorm apply -> q | k (row-major [B n][2 C], + bias) and the merged
+// value projection written transposed (vt [B][C][npad]); weights fragment-major (launch_sf_frag_major); x / cstats as in StEntryArgs
+struct AttnProjArgs {
+  int dtype = DT_F16;
+  int B = 0, n = 0, C = 0;
+  long npad = 0;
+  const void* x = nullptr; const float* cstats = nullptr;
+  const float* gn_gamma = nullptr; const float* gn_beta = nullptr; int groups = 0; float gn_eps = 1e-6f;
+  const void* w_qk = nullptr; const float* b_qk = nullptr;     // [2 C][C], bias [2 C]
+  const void* w_v = nullptr;                                   // [C][C] (no bias: the attention kernel's epilogue adds it)
+  void* qk = nullptr; void* vt = nullptr;
+};
+bool attn_proj_eligible(const AttnProjArgs& a);
+int launch_attn_proj(const AttnProjArgs& a, hipStream_t s);
 extern bool g_st_fuse;
 extern bool g_small_conv_fm;   // engine.cpp (plan switch 41)
+extern bool g_attn_proj;       // engine.cpp (plan switch 46)
 extern bool g_attn_fm;         // engine.cpp (plan switch 45)
 extern bool g_st_fuse_512;     // engine.cpp (plan switch 44, read at engine build)
 extern int g_st_tail_rows;     // engine.cpp (development key 43)
