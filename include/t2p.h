@@ -206,10 +206,11 @@ int t2p_op_st_entry(int dtype, const void* x, const float* col_stats, int groups
 /* the projections of an AttnBlockpp (layers.py:160-167) in ONE launch over 32-row blocks at C = 256: h = GroupNorm(x) (statistics from
  * col_stats as in t2p_op_st_entry, or x already normalised), qk [batch n][2 C] = h [W_0 | W_1]^T + b (NIN_0 | NIN_1), and
  * vt [batch][C][npad] = (h W_v^T)^T: the value projection written transposed (the engine passes NIN_2 . NIN_3 as W_v).
- * x, w_qk [2 C][C], w_v [C][C], qk, vt in the 16-bit compute dtype.  n % 32 == 0, batch n <= 8192, npad >= n, npad % 4 == 0 */
+ * x, w_qk [2 C][C], w_v [C][C], qk, vt in the 16-bit compute dtype.  n % 32 == 0, batch n <= 8192, npad >= n, npad % 4 == 0.
+ * With k_fm (npad == n): the k half goes to k_fm and vt is written in the fragment-major order of t2p_op_attention_wide_fm instead */
 int t2p_op_attn_proj(int dtype, const void* x, const float* col_stats, int groups, const float* gn_gamma, const float* gn_beta,
-                     float gn_eps, const void* w_qk, const float* b_qk, const void* w_v, void* qk, void* vt, int64_t npad,
-                     int batch, int n, int C, void* stream);
+                     float gn_eps, const void* w_qk, const float* b_qk, const void* w_v, void* qk, void* vt, void* k_fm,
+                     int64_t npad, int batch, int n, int C, void* stream);
 /* the network's input convolution (pre_conv, ncsnpp.py:230: 3x3, C = 5 or 8 input channels -> nf) straight from the NCHW fp32
  * sample, in fp32 arithmetic: x [batch][C][H][W] fp32; w_tcn [3*3][C][nf] fp32 (tap-major); out NHWC [batch][H][W][nf] in
  * out_dtype.  col_stats (optional; W % 64 == 0, nf | 256): [batch H W / 64][nf][2] fp32 = (sum, sum of squares) of the fp32
@@ -248,7 +249,8 @@ int t2p_op_attention_wide(int dtype, const void* q, int64_t ldq, const void* k, 
                           int batch, int n, int d, float scale, void* stream);
 /* the same with k and vt FRAGMENT-MAJOR ([batch][n d] each: element (r, c) -- r = key, c = channel for k; r = channel, c = key for
  * vt -- at ((r / 32) (cols / 32) + c / 32) 1024 + ((c / 8) % 2) 512 + ((c / 16) % 2) 256 + (r % 32) 8 + c % 8): the kernel's fragment
- * loads are then 1 KiB contiguous.  d = 512, 512 < n <= 1024, n % 32 == 0.  Bit-identical to t2p_op_attention_wide. */
+ * loads are then 1 KiB contiguous.  d = 512 with 512 < n <= 1024, or d = 256 with n <= 256; n % 32 == 0.  Bit-identical to
+ * t2p_op_attention_wide. */
 int t2p_op_attention_wide_fm(int dtype, const void* q, int64_t ldq, const void* k_fm, const void* vt_fm, void* out, int out_f32,
                              const float* bias, const void* residual, int residual_16bit, float alpha, float* col_stats, int batch,
                              int n, int d, float scale, void* stream);

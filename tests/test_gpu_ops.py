@@ -641,12 +641,22 @@ def test_attention_block_projections_in_one_launch(lib, dt, B, n, with_stats):
     qk = torch.full((B, n, 2 * Cc), float("nan"), device="cuda", dtype=td)
     vt = torch.full((B, Cc, npad), float("nan"), device="cuda", dtype=td)
     check(lib, lib.t2p_op_attn_proj(dt, P(dev(x)), csp, G, P(dev(gamma)), P(dev(beta)), 1e-6, P(dev(w_qk)), P(dev(b_qk)), P(dev(w_v)), P(qk), P(vt),
-                                    npad, B, n, Cc, None))
+                                    None, npad, B, n, Cc, None))
     torch.cuda.synchronize()
     tol = 1.5e-3 if dt == 2 else 1.2e-2
     assert rel_l2(qk.float().cpu(), qk_ref) < tol
     assert rel_l2(vt[..., :n].float().cpu(), vt_ref) < tol
     assert torch.isnan(vt[..., n:].float()).all()                              # the padding columns are not touched
+    # the same with K and V^T fragment-major (the order attn_strip_kernel<.., FM> streams): the same values in another place
+    qk2 = torch.full((B, n, 2 * Cc), float("nan"), device="cuda", dtype=td)
+    kf = torch.full((B, n * Cc), float("nan"), device="cuda", dtype=td)
+    vf = torch.full((B, Cc * n), float("nan"), device="cuda", dtype=td)
+    check(lib, lib.t2p_op_attn_proj(dt, P(dev(x)), csp, G, P(dev(gamma)), P(dev(beta)), 1e-6, P(dev(w_qk)), P(dev(b_qk)), P(dev(w_v)), P(qk2), P(vf),
+                                    P(kf), n, B, n, Cc, None))
+    torch.cuda.synchronize()
+    assert torch.equal(qk2[..., :Cc].cpu(), qk[..., :Cc].cpu())
+    assert torch.equal(kf.cpu(), _frag_major(qk[..., Cc:].cpu().contiguous()))
+    assert torch.equal(vf.cpu(), _frag_major(vt[..., :n].cpu().contiguous()))
 
 
 def _frag_major(x):
@@ -698,11 +708,10 @@ def test_gemm_fragment_major_output(lib, dt):
 
 
 @pytest.mark.parametrize("dt", [1, 2])
-@pytest.mark.parametrize("B,n", [(2, 1024), (3, 640)])
-def test_wide_head_attention_on_fragment_major_operands(lib, dt, B, n):
+@pytest.mark.parametrize("B,n,d", [(2, 1024, 512), (3, 640, 512), (3, 256, 256), (2, 64, 256)])
+def test_wide_head_attention_on_fragment_major_operands(lib, dt, B, n, d):
     """t2p_op_attention_wide_fm: the same kernel reading K and V^T fragment-major: bit-identical to the row-major form."""
     td = TDT[dt]
-    d = 512
     g = torch.Generator().manual_seed(n + dt)
     qk = torch.randn(B, n, 2 * d, generator=g).to(td)
     vt = torch.randn(B, d, n, generator=g).to(td)

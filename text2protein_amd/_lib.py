@@ -72,7 +72,7 @@ SIGNATURES = {
     "t2p_op_gemm_frag_major": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "t2p_op_small_conv_groupnorm": (_i, [_i, _vp, _vp, _i64, _vp, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _i,
                                          _i, _i, _i, _i, _i, _vp]),
-    "t2p_op_attn_proj": (_i, [_i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "t2p_op_attn_proj": (_i, [_i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "t2p_op_st_entry": (_i, [_i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                              _i, _i, _i, _vp]),
     "t2p_op_input_conv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -635,7 +635,8 @@ static int launch_strip_t(const StripArgs& a, int B, hipStream_t s) {
 }
 
 bool attention_strip_frag_major_ok(int dtype, int n, int d) {
-  return (dtype == DT_F16 || dtype == DT_BF16) && d == 512 && n > 512 && n <= 1024 && n % 32 == 0;
+  if ((dtype != DT_F16 && dtype != DT_BF16) || n % 32 != 0) return false;
+  return (d == 512 && n > 512 && n <= 1024) || (d == 256 && n <= 256);
 }
 int launch_attention_strip(int dtype, const void* q, long ldq, const void* k, long ldk, const void* vt, long ldvt, void* out, long ldo,
                            int B, int n, int d, float scale, hipStream_t s, const StripEpilogue* ep) {
@@ -660,8 +661,12 @@ int launch_attention_strip(int dtype, const void* q, long ldq, const void* k, lo
   }
   const int nkt = n <= 256 ? 1 : (n <= 512 ? 2 : 4);
   if (ep && ep->frag_major) {     // K and V^T fragment-major: [B][n d] each (the 32 x 32 level of the C = 512 configurations)
-    T2P_REQUIRE(attention_strip_frag_major_ok(dtype, n, d), "wide-head attention: fragment-major operands need d = 512, 512 < n <= 1024, n % 32 == 0");
+    T2P_REQUIRE(attention_strip_frag_major_ok(dtype, n, d), "wide-head attention: fragment-major operands need d = 512 with 512 < n <= 1024 or d = 256 with n <= 256, n % 32 == 0");
     a.sk_b = (long)n * d; a.svt_b = (long)n * d;
+    if (d == 256) {
+      if (dtype == DT_BF16) return launch_strip_t<bf16_t, 256, 1, true>(a, B, s);
+      return launch_strip_t<f16_t, 256, 1, true>(a, B, s);
+    }
     if (dtype == DT_BF16) return launch_strip_t<bf16_t, 512, 4, true>(a, B, s);
     return launch_strip_t<f16_t, 512, 4, true>(a, B, s);
   }

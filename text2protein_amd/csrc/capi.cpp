@@ -308,11 +308,12 @@ int t2p_op_st_entry(int dtype, const void* x, const float* col_stats, int groups
 }
 
 int t2p_op_attn_proj(int dtype, const void* x, const float* col_stats, int groups, const float* gn_gamma, const float* gn_beta, float gn_eps,
-                     const void* w_qk, const float* b_qk, const void* w_v, void* qk, void* vt, int64_t npad, int batch, int n, int C, void* stream) {
+                     const void* w_qk, const float* b_qk, const void* w_v, void* qk, void* vt, void* k_fm, int64_t npad, int batch, int n, int C,
+                     void* stream) {
   API_BEGIN
   AttnProjArgs e;
   e.dtype = dtype; e.B = batch; e.n = n; e.C = C; e.npad = npad; e.x = x; e.cstats = col_stats; e.groups = groups; e.gn_gamma = gn_gamma;
-  e.gn_beta = gn_beta; e.gn_eps = gn_eps; e.b_qk = b_qk; e.qk = qk; e.vt = vt;
+  e.gn_beta = gn_beta; e.gn_eps = gn_eps; e.b_qk = b_qk; e.qk = qk; e.vt = vt; e.k_fm = k_fm;
   T2P_REQUIRE(attn_proj_eligible(e), "attn_proj: C = 256, 16-bit dtype, n % 32 == 0 (64 with column sums), batch n <= 8192, npad % 4 == 0");
   void* fm = nullptr;
   T2P_HIP_CHECK(hipMalloc(&fm, (size_t)3 * C * C * 2));
@@ -457,7 +458,7 @@ int t2p_op_attention_wide_fm(int dtype, const void* q, int64_t ldq, const void* 
                              int d, float scale, void* stream) {
   API_BEGIN
   T2P_REQUIRE(attention_strip_frag_major_ok(dtype, n, d) && attention_strip_eligible(dtype, 1, n, n, d, ldq, d, n, d),
-              "attention_wide_fm: 16-bit dtypes, d = 512, 512 < n <= 1024, n % 32 == 0");
+              "attention_wide_fm: 16-bit dtypes, d = 512 with 512 < n <= 1024 or d = 256 with n <= 256, n % 32 == 0");
   StripEpilogue ep;
   ep.bias = bias; ep.residual = residual; ep.r_lowp = residual_16bit; ep.ldr = d; ep.alpha = alpha; ep.out_f32 = out_f32; ep.col_stats = col_stats;
   ep.frag_major = 1;

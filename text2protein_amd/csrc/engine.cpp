@@ -1113,6 +1113,12 @@ int Engine::attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
       POOL_GET(qk2, char*, (size_t)rows * 2 * C * es);
       POOL_GET(vt2, void*, (size_t)B * C * npad * es);
       e.qk = qk2; e.vt = vt2;
+      void* kfm2 = nullptr;
+      if (g_attn_fm && npad == n && attention_strip_frag_major_ok(dt, n, C)) {     // K and V^T in the order the attention kernel streams them
+        kfm2 = pool_.get((size_t)rows * C * es);
+        if (!kfm2) return T2P_ERR_HIP;
+        e.k_fm = kfm2;
+      }
       T2P_TRY(launch_attn_proj(e, s));
       if (normed) { pool_.put(x.pre_norm); x.pre_norm = nullptr; }
       const float att_scale2 = 1.f / std::sqrt((float)C);
@@ -1125,7 +1131,10 @@ int Engine::attn_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {
       StripEpilogue ep;
       ep.bias = L.v3.b; ep.residual = x.p; ep.r_lowp = 1; ep.ldr = C; ep.alpha = cfg_.skip_rescale ? 0.70710678118654752440f : 1.f;
       ep.out_f32 = olp ? 0 : 1; ep.col_stats = y_stats;
-      T2P_TRY(launch_attention_strip(dt, qk2, 2 * C, qk2 + (size_t)C * es, 2 * C, vt2, npad, y, C, B, n, C, att_scale2, s, &ep));
+      ep.frag_major = kfm2 ? 1 : 0;
+      if (kfm2) T2P_TRY(launch_attention_strip(dt, qk2, 2 * C, kfm2, C, vt2, npad, y, C, B, n, C, att_scale2, s, &ep));
+      else T2P_TRY(launch_attention_strip(dt, qk2, 2 * C, qk2 + (size_t)C * es, 2 * C, vt2, npad, y, C, B, n, C, att_scale2, s, &ep));
+      pool_.put(kfm2);
       pool_.put(qk2);
       pool_.put(vt2);
       *out = Act{y, C, x.H, x.W, y_stats, olp};

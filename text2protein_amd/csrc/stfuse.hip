@@ -525,9 +525,16 @@ __global__ __launch_bounds__(512) void attn_proj_kernel(const AttnProjArgs a) {
                                             [&](int i, int ct, sf_f32x4 (&acc)[2], const float4 bb) {
       const int col = ct * 16 + 4 * g4;
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-        *(sf_u32x2*)(Q + (long)(m0 + rt * 16 + l16) * (2 * C) + col) =
-            sf_u32x2{sf_pack2<TC>(acc[rt][0] + bb.x, acc[rt][1] + bb.y), sf_pack2<TC>(acc[rt][2] + bb.z, acc[rt][3] + bb.w)};
+      for (int rt = 0; rt < 2; ++rt) {
+        const sf_u32x2 o = {sf_pack2<TC>(acc[rt][0] + bb.x, acc[rt][1] + bb.y), sf_pack2<TC>(acc[rt][2] + bb.z, acc[rt][3] + bb.w)};
+        if (a.k_fm && col >= C) {              // the k half fragment-major per sample (GemmParams::c_frag's order): an 8-byte half of a chunk
+          const int c = col - C, rl = m0 - b * a.n + rt * 16 + l16;
+          *(sf_u32x2*)((TC*)a.k_fm + (long)b * a.n * C + ((long)(rl >> 5) * (C / 32) + (c >> 5)) * 1024 + ((c >> 3) & 1) * 512 + ((c >> 4) & 1) * 256 +
+                       (rl & 31) * 8 + (c & 7)) = o;
+        } else {
+          *(sf_u32x2*)(Q + (long)(m0 + rt * 16 + l16) * (2 * C) + col) = o;
+        }
+      }
     });
   }
   // V^T [B][C][npad]: activations first, so a lane holds 4 consecutive keys of one channel: an 8-byte piece of a V^T row
@@ -538,9 +545,16 @@ __global__ __launch_bounds__(512) void attn_proj_kernel(const AttnProjArgs a) {
                                               [&](int i, int ct, sf_f32x4 (&acc)[2], const float4) {
       const int ch = ct * 16 + l16;
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-        *(sf_u32x2*)(VT + (long)ch * a.npad + rt * 16 + 4 * g4) =
-            sf_u32x2{sf_pack2<TC>(acc[rt][0], acc[rt][1]), sf_pack2<TC>(acc[rt][2], acc[rt][3])};
+      for (int rt = 0; rt < 2; ++rt) {
+        const sf_u32x2 o = {sf_pack2<TC>(acc[rt][0], acc[rt][1]), sf_pack2<TC>(acc[rt][2], acc[rt][3])};
+        if (a.k_fm) {                          // V^T fragment-major too: rows = channels, columns = keys (npad == n)
+          const int key = m0 - b * a.n + rt * 16 + 4 * g4;
+          *(sf_u32x2*)((TC*)a.vt + (long)b * a.n * C + ((long)(ch >> 5) * (a.n >> 5) + (key >> 5)) * 1024 + ((key >> 3) & 1) * 512 +
+                       ((key >> 4) & 1) * 256 + (ch & 31) * 8 + (key & 7)) = o;
+        } else {
+          *(sf_u32x2*)(VT + (long)ch * a.npad + rt * 16 + 4 * g4) = o;
+        }
+      }
     });
   }
 }
@@ -549,6 +563,7 @@ bool attn_proj_eligible(const AttnProjArgs& a) {
   if (!g_st_fuse || (a.dtype != DT_F16 && a.dtype != DT_BF16) || a.C != 256) return false;
   if (a.n % SF_ROWS != 0 || (long)a.B * a.n > 8192 || a.npad % 4 != 0 || a.npad < a.n) return false;
   if (a.cstats && (a.n % 64 != 0 || a.groups <= 0 || a.C % a.groups != 0)) return false;
+  if (a.k_fm && a.npad != a.n) return false;
   return true;
 }
 int launch_attn_proj(const AttnProjArgs& a, hipStream_t s) {

@@ -208,6 +208,8 @@ struct AttnProjArgs {
   const void* w_qk = nullptr; const float* b_qk = nullptr;     // [2 C][C], bias [2 C]
   const void* w_v = nullptr;                                   // [C][C] (no bias: the attention kernel's epilogue adds it)
   void* qk = nullptr; void* vt = nullptr;
+  void* k_fm = nullptr;      // optional: the k half goes here FRAGMENT-MAJOR ([B][n C]) and vt is written fragment-major as well (npad == n):
+                             // the operands of attn_strip_kernel<.., FM> (attention_strip_frag_major_ok)
 };
 bool attn_proj_eligible(const AttnProjArgs& a);
 int launch_attn_proj(const AttnProjArgs& a, hipStream_t s);
