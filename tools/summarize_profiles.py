@@ -15,7 +15,20 @@ import shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+_DEMANGLED = {}
+
+
 def short(name):
+    if name.startswith("_Z"):          # rocprofv3 leaves names with _Float16 pointers mangled: ask llvm-cxxfilt
+        if name not in _DEMANGLED:
+            import shutil
+            import subprocess
+            tool = shutil.which("llvm-cxxfilt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+            try:
+                _DEMANGLED[name] = subprocess.run([tool, name], capture_output=True, text=True, timeout=10).stdout.strip() or name
+            except Exception:
+                _DEMANGLED[name] = name
+        name = _DEMANGLED[name]
     return name.split("(")[0].replace("void t2p::", "").replace("t2p::", "")
 
 
