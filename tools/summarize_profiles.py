@@ -28,6 +28,29 @@ def short(name):
                 _DEMANGLED[name] = subprocess.run([tool, name], capture_output=True, text=True, timeout=10).stdout.strip() or name
             except Exception:
                 _DEMANGLED[name] = name
+            if _DEMANGLED[name].startswith("_Z"):      # (this llvm-cxxfilt does not know DF16_ either): kernel name + template arguments by hand
+                import re
+                m = re.match(r"_ZN3t2p(\d+)", name)
+                if m:
+                    n0 = m.end()
+                    base = name[n0:n0 + int(m.group(1))]
+                    rest, args = name[n0 + int(m.group(1)):], []
+                    if rest.startswith("I"):
+                        rest = rest[1:]
+                        while rest and not rest.startswith("E"):
+                            mi = re.match(r"Li(\d+)E", rest) or re.match(r"Lb([01])E", rest)
+                            mt = re.match(r"NS_(\d+)", rest)
+                            if mi:
+                                args.append(("true" if mi.group(1) == "1" else "false") if rest.startswith("Lb") else mi.group(1))
+                                rest = rest[mi.end():]
+                            elif mt:
+                                k = mt.end()
+                                args.append(rest[k:k + int(mt.group(1))])
+                                rest = rest[k + int(mt.group(1)):]
+                                rest = rest[1:] if rest.startswith("E") and not rest.startswith("EE") else rest
+                            else:
+                                break
+                    _DEMANGLED[name] = base + ("<" + ", ".join(args) + ">" if args else "")
         name = _DEMANGLED[name]
     return name.split("(")[0].replace("void t2p::", "").replace("t2p::", "")
 
