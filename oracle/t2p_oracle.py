@@ -12,6 +12,9 @@ What it restates (all citations relative to /root/reference):
   * the VE / VP SDE tables and discretisations        score_sde_pytorch/sde_lib.py:106-157,199-245
   * ``get_score_fn``                                  score_sde_pytorch/models/utils.py:126-176
   * the predictor-corrector loop ``pc_sampler``       score_sde_pytorch/sampling.py:157-199,245-289
+  * the training step: ``loss_fn``  score_sde_pytorch/losses.py:66-138
+    ``get_optimizer`` / ``optimize_fn`` / ``step_fn``  score_sde_pytorch/losses.py:26-51,140-186
+    ``ExponentialMovingAverage.update``               score_sde_pytorch/models/ema.py:32-49
 
 Everything is written as plain functions over a ``{state-dict name: tensor}`` mapping (float32
 torch CPU ops; the float64 ``sigmas`` tail of the reference is kept), in the reference's NCHW
@@ -99,8 +102,9 @@ def _down2(x):     # naive_downsample_2d, layers.py:185-188
     return x.reshape(n, c, h // 2, 2, w // 2, 2).mean(dim=(3, 5))
 
 
-def resblock(P, p, x, temb, up=False, down=False, skip_rescale=True):
-    """ResnetBlockBigGANpp.forward (layers.py:303-327), eval mode (dropout = identity)."""
+def resblock(P, p, x, temb, up=False, down=False, skip_rescale=True, dropout=None):
+    """ResnetBlockBigGANpp.forward (layers.py:303-327); ``dropout`` = None (eval mode: identity) or a callable
+    ``h -> Dropout_0(h)`` (training mode, layers.py:318)."""
     h = F.silu(_gn(P, p + ".GroupNorm_0", x))
     if up:
         h, x = _up2(h), _up2(x)
@@ -109,6 +113,8 @@ def resblock(P, p, x, temb, up=False, down=False, skip_rescale=True):
     h = F.conv2d(h, P[p + ".Conv_0.weight"], P[p + ".Conv_0.bias"], padding=1)
     h = h + F.linear(F.silu(temb), P[p + ".Dense_0.weight"], P[p + ".Dense_0.bias"])[:, :, None, None]
     h = F.silu(_gn(P, p + ".GroupNorm_1", h))
+    if dropout is not None:
+        h = dropout(h)
     h = F.conv2d(h, P[p + ".Conv_1.weight"], P[p + ".Conv_1.bias"], padding=1)
     if (p + ".Conv_2.weight") in P:
         x = F.conv2d(x, P[p + ".Conv_2.weight"], P[p + ".Conv_2.bias"])
@@ -210,10 +216,11 @@ def unet_plan(config):
     return inputs, mid, outs
 
 
-def unet_forward(P, config, x, labels, context, taps=None):
+def unet_forward(P, config, x, labels, context, taps=None, dropout=None):
     """UNetModel.forward (ncsnpp.py:220-263).  Returns float64 like the reference (``h / sigmas``).
 
-    ``taps``: optional dict filled with intermediate tensors (for per-block golden checks)."""
+    ``taps``: optional dict filled with intermediate tensors (for per-block golden checks).
+    ``dropout``: training mode only -- the callable every residual block applies as its ``Dropout_0``."""
     inputs, mid, outs = unet_plan(config)
     nf = config.model.nf
     heads = config.model.n_heads
@@ -231,7 +238,7 @@ def unet_forward(P, config, x, labels, context, taps=None):
     def run_stage(stage, h):
         for kind, prefix, is_up, is_down in stage:
             if kind == "res":
-                h = resblock(P, prefix, h, temb, up=is_up, down=is_down, skip_rescale=sr)
+                h = resblock(P, prefix, h, temb, up=is_up, down=is_down, skip_rescale=sr, dropout=dropout)
             elif kind == "attn":
                 h = attnblock(P, prefix, h, skip_rescale=sr)
             else:
@@ -389,6 +396,104 @@ def pc_sampler_vp(P, config, shape, context, condition=None, eps=1e-3, noise_fn=
                 trace.append((x.clone(), x_mean.clone()))
         x_mean = torch.where(cmask, x_mean, x_initial).float()
         return (x_mean if s.noise_removal else x), N * (s.n_steps_each + 1)
+
+
+# --------------------------------------------------------------------------------------------
+# training step.  PARITY PINNING: score_sde_pytorch/losses.py does not import here
+# (module-level `import biotite`), so the loss body below is a line-by-line restatement; it is pinned by
+# tests/golden/make_golden_train.py, which evaluates the same expressions on the REFERENCE UNetModel
+# (through the reference's own get_score_fn / VESDE.marginal_prob / ExponentialMovingAverage and
+# torch.optim.Adam as get_optimizer builds it) and stores loss, gradients and post-step parameters.
+# --------------------------------------------------------------------------------------------
+def ve_marginal_std(t, sigma_min, sigma_max):
+    """VESDE.marginal_prob (sde_lib.py:225-228): mean = x, std = sigma_min (sigma_max / sigma_min)^t."""
+    return sigma_min * (sigma_max / sigma_min) ** t
+
+
+def training_mask(coords_6d, mask_pair, condition, mask_inpaint=None):
+    """losses.py:113-125: conditional_mask from the config's condition list, times the pair mask."""
+    cm = torch.ones_like(coords_6d).bool()
+    for c in (condition or []):
+        if c == "length":
+            cm[:, -1] = False
+        elif c == "ss":
+            cm[:, 4:7] = False
+        elif c == "inpainting":
+            cm = cm * mask_inpaint.unsqueeze(1)
+    return mask_pair.unsqueeze(1) * cm
+
+
+def sde_loss_ve(P, config, coords_6d, mask_pair, context, t, z, condition=None, mask_inpaint=None, dropout=None):
+    """loss_fn of get_sde_loss_fn (losses.py:105-134) for the VE SDE with t and z given (the reference draws
+    them with torch.rand / randn_like, :106-107); get_score_fn's VE branch (models/utils.py:159-171)."""
+    m = config.model
+    std = ve_marginal_std(t, m.sigma_min, m.sigma_max)                                  # :108
+    perturbed = coords_6d + std[:, None, None, None] * z                               # :109
+    mask = training_mask(coords_6d, mask_pair, condition, mask_inpaint)                # :111-123
+    num_elem = mask.reshape(mask.shape[0], -1).sum(dim=-1)                             # :124
+    perturbed = torch.where(mask, perturbed, coords_6d)                                # :126
+    score = unet_forward(P, config, perturbed, ve_label(t, m.num_scales), context, dropout=dropout)   # :127
+    losses = torch.square(score * std[:, None, None, None] + z) * mask                 # :128
+    losses = torch.sum(losses.reshape(losses.shape[0], -1), dim=-1)                    # :129
+    losses = losses / (num_elem + 1e-8)                                                # :130
+    return torch.mean(losses)                                                          # :131
+
+
+def warmup_lr(config, step):
+    """optimize_fn (losses.py:44-46): lr min(step / warmup, 1) with the step count BEFORE this update."""
+    o = config.optim
+    return o.lr * float(np.minimum(step / o.warmup, 1.0)) if o.warmup > 0 else o.lr
+
+
+def clip_coef(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (losses.py:47-48): total 2-norm, coefficient clamped to 1."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    return torch.clamp(max_norm / (total + 1e-6), max=1.0), total
+
+
+def adam_update(p, g, m, v, k, lr, beta1, beta2, eps, weight_decay=0.0):
+    """torch.optim.Adam (get_optimizer, losses.py:26-36), update number k >= 1, in place on (p, m, v)."""
+    if weight_decay:
+        g = g + weight_decay * p
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    denom = (v.sqrt() / math.sqrt(1 - beta2 ** k)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / (1 - beta1 ** k))
+
+
+def ema_decay(rate, num_updates):
+    """ExponentialMovingAverage.update (ema.py:41-44): num_updates already incremented."""
+    return min(rate, (1 + num_updates) / (10 + num_updates))
+
+
+def train_step(P, state, config, batch, t, z, condition=None, dropout=None):
+    """step_fn of get_step_fn, train=True (losses.py:165-176): zero_grad, loss, backward, optimize_fn, step += 1,
+    ema.update.  ``P``: name -> leaf tensor (requires_grad); ``state``: dict(step, adam_k, m, v, ema, ema_updates) -- ``step`` is
+    state['step'] of the reference (drives the warm-up only), ``adam_k`` the optimizer's own update count.  Returns the loss
+    and the (unclipped) gradients by name."""
+    o = config.optim
+    for w in P.values():
+        w.grad = None
+    loss = sde_loss_ve(P, config, batch["coords_6d"], batch["mask_pair"], batch["context"], t, z, condition,
+                       batch.get("mask_inpaint"), dropout=dropout)
+    loss.backward()
+    names = list(P)
+    raw = {n: P[n].grad.detach().clone() for n in names}
+    lr = warmup_lr(config, state["step"])
+    if o.grad_clip >= 0:
+        c, _ = clip_coef([P[n].grad for n in names], o.grad_clip)
+        for n in names:
+            P[n].grad.mul_(c)
+    state["step"] += 1
+    state["adam_k"] += 1
+    with torch.no_grad():
+        for n in names:
+            adam_update(P[n], P[n].grad, state["m"][n], state["v"][n], state["adam_k"], lr, o.beta1, 0.999, o.eps, o.weight_decay)
+        state["ema_updates"] += 1
+        d = ema_decay(config.model.ema_rate, state["ema_updates"])
+        for n in names:
+            state["ema"][n].sub_((1.0 - d) * (state["ema"][n] - P[n]))
+    return loss.detach(), raw
 
 
 # --------------------------------------------------------------------------------------------

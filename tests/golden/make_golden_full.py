@@ -21,6 +21,9 @@ Complements make_golden.py (tiny shapes, per-block taps) with what the benchmark
                          ones, and the score the reference computes after restore_checkpoint + ema.copy_to
                          (sampling_6d.py:64-73).
 
+  run1000_cond_length_inpainting.npz / run1000_test_config_L128.npz   (round 4) the same for cond_length_inpainting.yml
+                         (C = 8, length 100 + inpainting "1:5,10:15" on synthetic coords_6d: a shard of BASELINE configs[4]) and for
+                         test_config.yml at the benchmark's own L = 128 (one chain: configs[1]).
   run1000_cond_length.npz   the horizon the metric is quoted on: COMPLETE N = 1000 runs of the reference sampler on
   run1000_test_config.npz   counter-based noise, B = 2: cond_length.yml at L = 128 with the `length` condition
                          (100 residues: a shard of BASELINE configs[2]) and test_config.yml at L = 64 (no condition);
@@ -133,26 +136,39 @@ def run100_fixture():
                         oracle_rel_l2=np.float64(err))
 
 
-RUN1000 = {   # stem -> (yaml, L, text tokens, noise seed, context seed, length condition or None)
-    "cond_length": ("cond_length.yml", 128, 64, 31337, 21, 100),
-    "test_config": ("test_config.yml", 64, 64, 31338, 22, None),
+RUN1000 = {   # stem -> (yaml, L, chains, text tokens, noise seed, context seed, length condition or None, inpainting ranges or None)
+    "cond_length": ("cond_length.yml", 128, 2, 64, 31337, 21, 100, None),
+    "test_config": ("test_config.yml", 64, 2, 64, 31338, 22, None, None),
+    # round 4: the two BASELINE configurations the horizon was not yet pinned on
+    "cond_length_inpainting": ("cond_length_inpainting.yml", 128, 2, 64, 31339, 23, 100, "1:5,10:15"),   # configs[4], C = 8
+    "test_config_L128": ("test_config.yml", 128, 1, 64, 31340, 24, None, None),                            # configs[1]'s own L
 }
+INPAINT_COORDS_SEED = 3     # coords_6d ~ U(-1, 1) = synth.uniform_pm1(3, "coords_6d", B C L L), regenerated on the test side
 
 
-def run1000_fixture(stem):
-    """N = 1000 (2000 score evaluations, 2001 draws), B = 2: the reference's pc_sampler, sampling.py:245-289."""
-    fname, L, T, seed, cseed, length = RUN1000[stem]
-    B, N = 2, 1000
-    cfg = ref_config(fname, L, N)
-    model, _ = reference_model(cfg, 0)
-    C = cfg.data.num_channels
-    shape = (B, C, L, L)
-    ctx = synth.synth_context(B, T, cfg.model.context_dim, cseed)
+def run1000_condition(B, C, L, length, mask_info):
+    """The condition dict pc_sampler reads (sampling.py:260-275); tensors only."""
     cond = {}
     if length is not None:
         m = torch.zeros(B, L, L).bool()
         m[:, :length, :length] = True
         cond["length"] = m
+    if mask_info is not None:
+        coords = torch.from_numpy(synth.uniform_pm1(INPAINT_COORDS_SEED, "coords_6d", B * C * L * L).reshape(B, C, L, L))
+        cond["inpainting"] = {"coords_6d": coords, "mask_inpaint": O.selected_mask(mask_info, B, L)}
+    return cond
+
+
+def run1000_fixture(stem):
+    """N = 1000 (2000 score evaluations, 2001 draws): the reference's pc_sampler, sampling.py:245-289."""
+    fname, L, B, T, seed, cseed, length, mask_info = RUN1000[stem]
+    N = 1000
+    cfg = ref_config(fname, L, N)
+    model, _ = reference_model(cfg, 0)
+    C = cfg.data.num_channels
+    shape = (B, C, L, L)
+    ctx = synth.synth_context(B, T, cfg.model.context_dim, cseed)
+    cond = run1000_condition(B, C, L, length, mask_info)
     sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=N)
     fn = sampling.get_sampling_fn(cfg, sde, shape, 1e-5)
     noise = CounterNoise(seed)
@@ -168,7 +184,8 @@ def run1000_fixture(stem):
           f"{float(ref.pow(2).mean().sqrt()):.4g}", flush=True)
     np.savez_compressed(os.path.join(HERE, f"run1000_{stem}.npz"), sample=ref.numpy(), nfe=np.int64(nfe),
                         noise_seed=np.int64(seed), B=np.int64(B), L=np.int64(L), N=np.int64(N), T=np.int64(T),
-                        context_seed=np.int64(cseed), length=np.int64(-1 if length is None else length))
+                        context_seed=np.int64(cseed), length=np.int64(-1 if length is None else length),
+                        mask_info=np.str_(mask_info or ""), coords_seed=np.int64(INPAINT_COORDS_SEED))
 
 
 def ss_fixture():

@@ -91,3 +91,82 @@ def cfg_ckpt():
     """Small enough for a committed .pth (about 1 MB with the EMA copy)."""
     return tiny_config(**{"model.nf": 8, "model.ch_mult": [4], "model.attn_resolutions": [], "data.max_res_num": 8,
                           "model.n_heads": 2, "model.context_dim": 16, "model.num_scales": 10})
+
+
+# ---- training-step fixtures (tests/golden/make_golden_train.py writes them) ------------------------------------------
+def cfg_train_tiny():
+    """The tiny configuration in training trim: `length` condition, no dropout (the gradient check proper)."""
+    return tiny_config(**{"model.condition": ["length"], "model.dropout": 0.0, "model.num_scales": 50})
+
+
+def cfg_train_tinyB():
+    """Up / down blocks, two attention levels, C = 8, all three conditions, Dropout_0 active with counter-based keep-masks."""
+    return tiny_config(**{"model.ch_mult": [1, 1, 2], "model.num_res_blocks": 2, "data.num_channels": 8,
+                          "model.attn_resolutions": [4, 8], "model.n_heads": 2, "model.context_dim": 24, "model.nf": 32,
+                          "model.condition": ["length", "ss", "inpainting"], "model.dropout": 0.1, "model.num_scales": 50})
+
+
+TRAIN_CASES = {   # name -> what the fixture script and the tests share; step0 = state['step'] before the update (warm-up factor step0 / 5000)
+    "train_tiny": dict(config=cfg_train_tiny, seed=3, B=2, T=3, lengths=[12, 9], step0=2000, mask_info=None),
+    "train_tinyB": dict(config=cfg_train_tinyB, seed=4, B=3, T=5, lengths=[16, 11, 6], step0=7000, mask_info="1:3,6:8"),
+}
+
+
+def train_inputs(cfg, case):
+    """coords_6d ~ U(-1, 1) with the padding channel = the pair mask, pair masks of the given lengths, t ~ U(eps, 1), z ~ N(0, 1),
+    text context: all from the counter-hash generator, regenerated identically on both sides."""
+    from text2protein_amd import synth
+    B, T, seed = case["B"], case["T"], case["seed"]
+    C, L = cfg.data.num_channels, cfg.data.max_res_num
+    x = torch.from_numpy(synth.uniform_pm1(seed, "train_coords", B * C * L * L).reshape(B, C, L, L))
+    mp = torch.zeros(B, L, L).bool()
+    for b, n in enumerate(case["lengths"]):
+        mp[b, :n, :n] = True
+    x = x * mp.unsqueeze(1)
+    x[:, -1] = mp.float()
+    u = torch.from_numpy((synth.uniform_pm1(seed, "train_t", B).astype(np.float64) + 1.0) / 2.0).float()
+    t = u * (1.0 - 1e-5) + 1e-5                               # losses.py:106 with sde.T = 1, eps = 1e-5
+    z = torch.from_numpy(synth.normal(seed, "train_z", B * C * L * L).reshape(B, C, L, L))
+    out = dict(coords_6d=x, mask_pair=mp, t=t, z=z, context=synth.synth_context(B, T, cfg.model.context_dim, seed + 31))
+    if case.get("mask_info"):
+        m = torch.zeros(B, L)
+        for r in case["mask_info"].split(","):
+            a, b = r.split(":")
+            m[:, int(a):int(b) + 1] = 1
+        out["mask_inpaint"] = torch.logical_or(m.unsqueeze(-1), m.unsqueeze(1)).bool()
+    return out
+
+
+class CounterDropout:
+    """Dropout_0 keep-masks from the counter-hash generator: call k keeps element i iff uniform_pm1(seed, "drop<k>", n)[i] >= 2p - 1
+    (row-major over the NCHW tensor).  ``functional`` is patched over torch.nn.functional.dropout when the fixture is made
+    (calls with p == 0 or in eval mode pass through uncounted: FeedForward / CrossAttention hold Dropout(0.)); ``module`` is the
+    oracle's hook; ``mask(k, shape)`` gives the test the same mask to upload."""
+
+    def __init__(self, seed, p):
+        self.seed, self.p, self.k = int(seed), float(p), 0
+
+    def mask(self, k, shape):
+        from text2protein_amd import synth
+        n = int(np.prod(shape))
+        u = torch.from_numpy(synth.uniform_pm1(self.seed, f"drop{k}", n).reshape(tuple(shape)))
+        return u >= (2.0 * self.p - 1.0)
+
+    def module(self, h):
+        keep = self.mask(self.k, h.shape)
+        self.k += 1
+        return h * keep / (1.0 - self.p)
+
+    def functional(self, input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return input
+        assert abs(p - self.p) < 1e-12
+        return self.module(input)
+
+
+def projection(name, tensor, seed=99):
+    """<tensor, r> with r ~ U(-1, 1) keyed by the tensor's name: pins every element of a tensor with one stored number."""
+    from text2protein_amd import synth
+    v = torch.as_tensor(tensor).detach().double().reshape(-1)
+    r = torch.from_numpy(synth.uniform_pm1(seed, name + ":proj", v.numel())).double()
+    return float((v * r).sum())

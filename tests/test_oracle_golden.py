@@ -179,3 +179,37 @@ def test_oracle_at_full_size_cond_length():
     with torch.no_grad():
         s = O.unet_forward(synth.synth_state_dict(cfg, 0), cfg, x, labels, ctx)
     assert rel_l2(s, g["score"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["train_tiny", "train_tinyB"])
+def test_training_step_matches_reference_autograd(name):
+    """the oracle's restated loss / optimize_fn / EMA update (losses.py:26-51,105-134,165-176; ema.py:32-49) against
+    loss, gradients and post-step state produced by autograd through the REFERENCE UNetModel (tests/golden/make_golden_train.py):
+    every tensor through its norm and a random projection, one tensor of each kind element by element."""
+    from helpers import TRAIN_CASES, train_inputs, CounterDropout, projection
+    g = load_golden(name)
+    case = TRAIN_CASES[name]
+    cfg = case["config"]()
+    inp = train_inputs(cfg, case)
+    sd = synth.synth_state_dict(cfg, case["seed"])
+    names = [str(n) for n in g["names"]]
+    assert names == list(sd)                                    # parameters() order (the EMA shadow list follows it)
+    P = {n: w.clone().requires_grad_(True) for n, w in sd.items()}
+    state = dict(step=case["step0"], adam_k=0, ema_updates=0, m={n: torch.zeros_like(w) for n, w in sd.items()},
+                 v={n: torch.zeros_like(w) for n, w in sd.items()}, ema={n: w.clone() for n, w in sd.items()})
+    drop = CounterDropout(case["seed"], cfg.model.dropout)
+    loss, raw = O.train_step(P, state, cfg, dict(inp), inp["t"], inp["z"], cfg.model.condition,
+                             dropout=drop.module if cfg.model.dropout > 0 else None)
+    assert drop.k == int(g["n_dropout_calls"])
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    got = {"grads": raw, "post": {n: P[n].detach() for n in names}, "ema": state["ema"], "m": state["m"], "v": state["v"]}
+    for key, tol in (("grads", 1e-4), ("post", 1e-6), ("ema", 1e-6), ("m", 1e-4), ("v", 2e-4)):
+        for i, n in enumerate(names):
+            scale = max(float(g[key + "_norm"][i]), 1e-30)
+            assert abs(float(got[key][n].double().norm()) - float(g[key + "_norm"][i])) <= tol * scale, (key, n)
+            assert abs(projection(n, got[key][n]) - float(g[key + "_proj"][i])) <= tol * scale * 10, (key, n)
+    full = [k[5:] for k in g if k.startswith("grad:")]
+    assert len(full) >= 15
+    for n in full:
+        assert rel_l2(raw[n], g["grad:" + n]) < 1e-4, n
+        assert rel_l2(P[n].detach(), g["post:" + n]) < 1e-6, n
