@@ -147,6 +147,72 @@ int t2p_sampler_run(t2p_sampler* s, float* x, float* out, int prior_given, int n
  * on `stream` (not the default stream) and discarded, nothing executes; call after at least one eager step */
 int t2p_sampler_count_dispatches(t2p_sampler* s, float* x, float* x_mean, void* stream, int* n_out);
 
+/* ---- training step (first slice: fp32 arithmetic only, VE SDE) ------------------
+ * t2p_train_create      <- get_model + get_optimizer + ExponentialMovingAverage(model.parameters(), decay)
+ *                          (score_sde_pytorch/utils.py:4-9, losses.py:26-36, models/ema.py:13-30; train.py builds `state` from them)
+ * t2p_train_load_param  <- load_state_dict of one tensor; the EMA shadow starts as a copy (ema.py:28-29)
+ * t2p_train_loss        <- loss_fn(model, batch, condition)      (losses.py:105-134), optionally with loss.backward()
+ * t2p_train_step        <- step_fn(state, batch, condition), train=True (losses.py:165-176): zero_grad, loss, backward,
+ *                          optimize_fn (warm-up on state['step'], clip_grad_norm_, Adam: losses.py:41-49), step += 1, ema.update
+ * t2p_train_eval_loss   <- step_fn with train=False (losses.py:177-183): the loss under the EMA weights, model in eval mode
+ * The model runs in train mode (models/utils.py:116-118): Dropout_0 of every residual block is active when dropout > 0.       */
+typedef struct t2p_train_config {
+  double lr, beta1, eps, weight_decay;   /* optim.lr / beta1 / eps / weight_decay; beta2 = 0.999 as get_optimizer fixes it    */
+  double warmup;                          /* optim.warmup: lr * min(step / warmup, 1) when > 0                                   */
+  double grad_clip;                       /* optim.grad_clip: clip_grad_norm_(max_norm) when >= 0                                */
+  double ema_rate;                        /* model.ema_rate                                                                      */
+  double dropout;                         /* model.dropout (Dropout_0 of ResnetBlockBigGANpp, layers.py:293,318)                 */
+  double t_eps;                           /* smallest time drawn, 1e-5 (get_sde_loss_fn's eps)                                   */
+  int32_t cond_flags;                     /* model.condition: 1 length | 2 ss | 4 inpainting (losses.py:113-123)                */
+  uint64_t seed;                          /* on-device draws of t, z and the dropout masks when the batch does not supply them   */
+} t2p_train_config;
+
+typedef struct t2p_train_batch {
+  const float* coords_6d;      /* device fp32 (batch, C, L, L): batch["coords_6d"]                                               */
+  const uint8_t* mask_pair;    /* device uint8 (batch, L, L):   batch["mask_pair"]                                               */
+  const uint8_t* mask_inpaint; /* device uint8 (batch, L, L):   batch["mask_inpaint"], needed with the inpainting condition      */
+  const float* context;        /* device fp32 (batch, tokens, context_dim): llm.model.embed_tokens(caption tokens)              */
+  int32_t batch, tokens;
+  const float* t;              /* device fp32 [batch] or NULL = t ~ U(t_eps, 1) drawn on the device (losses.py:106)              */
+  const float* z;              /* device fp32 (batch, C, L, L) or NULL = z ~ N(0, 1) drawn on the device (losses.py:107)         */
+} t2p_train_batch;
+
+typedef struct t2p_trainer t2p_trainer;
+int t2p_train_create(const t2p_model_config* model, const t2p_train_config* train, t2p_trainer** out);
+void t2p_train_destroy(t2p_trainer* t);
+int t2p_train_num_params(const t2p_trainer* t);
+/* name and shape of tensor i in the reference's parameters() order (the order of the EMA shadow list and of the optimizer state) */
+int t2p_train_param_info(const t2p_trainer* t, int i, const char** name, int64_t shape[4], int* ndim);
+int t2p_train_load_param(t2p_trainer* t, const char* name, const float* host_data, const int64_t* shape, int ndim);
+/* which: 0 parameter, 1 gradient of the last backward pass (after t2p_train_step: as clip_grad_norm_ left it), 2 EMA shadow,
+ * 3 Adam exp_avg, 4 Adam exp_avg_sq; host buffers of the tensor's size, reference layout */
+int t2p_train_read(t2p_trainer* t, int which, const char* name, float* host_out);
+int t2p_train_write(t2p_trainer* t, int which, const char* name, const float* host_in);
+/* state['step'] (drives the warm-up), the optimizer's own update count (Adam bias correction) and ema.num_updates */
+int t2p_train_set_step(t2p_trainer* t, int64_t step, int64_t adam_updates, int64_t ema_updates);
+int t2p_train_get_step(const t2p_trainer* t, int64_t out3[3]);
+/* parity runs: keep-masks of Dropout_0 for the next pass, one device uint8 [batch][H][W][C] (NHWC, the block's own resolution and
+ * width) per residual block in forward order; n = 0 returns to on-device Philox masks */
+int t2p_train_set_dropout_masks(t2p_trainer* t, const uint8_t* const* device_masks, int n);
+/* loss_host: host float; score_out (optional): device fp32 (batch, C, L, L), the score the loss was computed from */
+int t2p_train_loss(t2p_trainer* t, const t2p_train_batch* batch, int backward, float* loss_host, float* score_out, void* stream);
+int t2p_train_step(t2p_trainer* t, const t2p_train_batch* batch, float* loss_host, void* stream);
+int t2p_train_eval_loss(t2p_trainer* t, const t2p_train_batch* batch, float* loss_host, void* stream);
+int64_t t2p_train_device_bytes(const t2p_trainer* t);
+/* the strided fp32 GEMM of the backward pass: C[z][m][n] = alpha sum_k A(z,m,k) B(z,k,n) + beta C, element strides as given
+ * (one stride of each operand must be 1); conv = 1: B is the 3x3 window gather of the NHWC map X [batch][H][W][conv_C] (weight
+ * gradient of a convolution: K = batch H W, N = 9 conv_C, sBk/sBn ignored, ldx = sBz0); ksplit 0 = chosen by the library (needs beta = 1 when > 1) */
+int t2p_op_tgemm(const float* A, int64_t sAm, int64_t sAk, const float* B, int64_t sBk, int64_t sBn, float* C, int64_t ldc, int M, int N,
+                 int K, int nz, int64_t sAz, int64_t sBz, int64_t sCz, float alpha, float beta, const float* bias_n, int ksplit, int conv,
+                 int H, int W, int conv_C, void* stream);
+/* backward halves of the operators (gradients accumulate into dx / dgamma / dbeta / du) */
+int t2p_op_groupnorm_backward(const float* x, const float* dy, const float* gamma, const float* beta, int silu, int batch, int HW, int C,
+                              int groups, float eps, float* dx, float* dgamma, float* dbeta, void* stream);
+int t2p_op_layernorm_backward(const float* x, const float* dy, const float* gamma, int64_t rows, int C, float eps, float* dx, float* dgamma,
+                              float* dbeta, void* stream);
+int t2p_op_softmax_backward(const float* P, float* dP_inout, int64_t rows, int n, float scale, void* stream);
+int t2p_op_geglu_backward(const float* u, const float* dy, float* du, int64_t rows, int inner, void* stream);
+
 /* ---- individual operators (parity tests call these through the same ABI) -------------------- */
 int t2p_op_gemm(int dtype, const void* A, int a_f32, const void* Bw, void* C, int c_f32, int M, int N, int K,
                 int64_t lda, int64_t ldb, int64_t ldc, const float* bias_n, const float* residual, float alpha,

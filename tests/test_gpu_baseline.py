@@ -46,7 +46,7 @@ def _model(cfg, sd, dtype):
 
 def _record(name, value):
     os.makedirs(OUT, exist_ok=True)
-    path = os.path.join(OUT, "r03_parity.json")
+    path = os.path.join(OUT, "r04_parity.json")
     data = json.load(open(path)) if os.path.exists(path) else {}
     data[name] = value
     json.dump(data, open(path, "w"), indent=1, sort_keys=True)

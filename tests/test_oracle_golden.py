@@ -203,9 +203,11 @@ def test_training_step_matches_reference_autograd(name):
     assert drop.k == int(g["n_dropout_calls"])
     assert abs(float(loss) - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
     got = {"grads": raw, "post": {n: P[n].detach() for n in names}, "ema": state["ema"], "m": state["m"], "v": state["v"]}
+    T = float(g["grad_total_norm"])     # exactly-zero gradients (key bias of an AttnBlockpp) hold rounding noise only: floor the scale
+    floor = {"grads": 3e-5 * T, "m": 3e-6 * T, "v": 1e-12 * T * T, "post": 0.0, "ema": 0.0}
     for key, tol in (("grads", 1e-4), ("post", 1e-6), ("ema", 1e-6), ("m", 1e-4), ("v", 2e-4)):
         for i, n in enumerate(names):
-            scale = max(float(g[key + "_norm"][i]), 1e-30)
+            scale = max(float(g[key + "_norm"][i]), floor[key], 1e-30)
             assert abs(float(got[key][n].double().norm()) - float(g[key + "_norm"][i])) <= tol * scale, (key, n)
             assert abs(projection(n, got[key][n]) - float(g[key + "_proj"][i])) <= tol * scale * 10, (key, n)
     full = [k[5:] for k in g if k.startswith("grad:")]

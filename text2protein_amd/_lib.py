@@ -35,6 +35,17 @@ class SamplerConfig(C.Structure):
                 ("seed", C.c_uint64)]
 
 
+class TrainConfig(C.Structure):          # t2p_train_config
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
+                ("warmup", C.c_double), ("grad_clip", C.c_double), ("ema_rate", C.c_double), ("dropout", C.c_double),
+                ("t_eps", C.c_double), ("cond_flags", C.c_int32), ("seed", C.c_uint64)]
+
+
+class TrainBatch(C.Structure):           # t2p_train_batch
+    _fields_ = [("coords_6d", C.c_void_p), ("mask_pair", C.c_void_p), ("mask_inpaint", C.c_void_p), ("context", C.c_void_p),
+                ("batch", C.c_int32), ("tokens", C.c_int32), ("t", C.c_void_p), ("z", C.c_void_p)]
+
+
 _vp, _i, _i64, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
 # name -> (restype, argtypes); every symbol declared in include/t2p.h
@@ -104,6 +115,26 @@ SIGNATURES = {
     "t2p_profile_layers_begin": (_i, []),
     "t2p_profile_layers_end": (_i, [C.c_char_p, C.c_int]),
     "t2p_op_convert": (_i, [_vp, _vp, _i, _i64, _vp]),
+    # training step
+    "t2p_train_create": (_i, [C.POINTER(ModelConfig), C.POINTER(TrainConfig), C.POINTER(_vp)]),
+    "t2p_train_destroy": (None, [_vp]),
+    "t2p_train_num_params": (_i, [_vp]),
+    "t2p_train_param_info": (_i, [_vp, _i, C.POINTER(C.c_char_p), C.POINTER(_i64), C.POINTER(_i)]),
+    "t2p_train_load_param": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
+    "t2p_train_read": (_i, [_vp, _i, C.c_char_p, _vp]),
+    "t2p_train_write": (_i, [_vp, _i, C.c_char_p, _vp]),
+    "t2p_train_set_step": (_i, [_vp, _i64, _i64, _i64]),
+    "t2p_train_get_step": (_i, [_vp, C.POINTER(_i64)]),
+    "t2p_train_set_dropout_masks": (_i, [_vp, C.POINTER(_vp), _i]),
+    "t2p_train_loss": (_i, [_vp, C.POINTER(TrainBatch), _i, C.POINTER(_f), _vp, _vp]),
+    "t2p_train_step": (_i, [_vp, C.POINTER(TrainBatch), C.POINTER(_f), _vp]),
+    "t2p_train_eval_loss": (_i, [_vp, C.POINTER(TrainBatch), C.POINTER(_f), _vp]),
+    "t2p_train_device_bytes": (_i64, [_vp]),
+    "t2p_op_tgemm": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i, _i, _i, _i, _i64, _i64, _i64, _f, _f, _vp, _i, _i, _i, _i, _i, _vp]),
+    "t2p_op_groupnorm_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "t2p_op_layernorm_backward": (_i, [_vp, _vp, _vp, _i64, _i, _f, _vp, _vp, _vp, _vp]),
+    "t2p_op_softmax_backward": (_i, [_vp, _vp, _i64, _i, _f, _vp]),
+    "t2p_op_geglu_backward": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
 }
 
 _lib = None

@@ -11,9 +11,10 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libt2p_hip.so")
 LIB_ABLATION = os.path.join(CSRC, "libt2p_hip_ablation.so")   # measurement builds only (tools/bench_conv.py --ablation)
-SOURCES = ["gemm.hip", "kernels.hip", "attention.hip", "smallconv.hip", "stfuse.hip", "engine.cpp", "capi.cpp"]
+SOURCES = ["gemm.hip", "kernels.hip", "attention.hip", "smallconv.hip", "stfuse.hip", "engine.cpp", "capi.cpp",
+           "train_kernels.hip", "train.cpp", "train_capi.cpp"]
 GEMM_PARTS = 7          # gemm.hip is compiled once per -DT2P_GEMM_PART=k: the LDS-DMA instantiations build in parallel
-HEADERS = ["t2p_common.h", "t2p_kernels.h", "engine.h", os.path.join("..", "..", "include", "t2p.h")]
+HEADERS = ["t2p_common.h", "t2p_kernels.h", "engine.h", "train_kernels.h", "train.h", os.path.join("..", "..", "include", "t2p.h")]
 ARCH = "gfx950"
 
 

@@ -172,6 +172,7 @@ class Engine {
   const float* tb_ = nullptr;   // per-eval temb biases [R][temb_total_]
   long tb_ld_ = 0;
   friend class Sampler;
+  friend class Trainer;     // train.cpp: reads the block list and the parameter table (Engine::build), nothing else
 };
 
 class Sampler {
