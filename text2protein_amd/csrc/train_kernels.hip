@@ -52,17 +52,27 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs p, const int
   if (BNC) { bn = tid % BN; bk = tid / BN; bkstep = 256 / BN; bnstep = 0; }
   else     { bk = tid % BK; bn = tid / BK; bkstep = 0; bnstep = 256 / BK; }
 
-  // convolution gather: this thread's column = (tap, channel) is fixed (BNC staging)
+  // convolution gather: this thread's column = (tap, channel) is fixed (BNC staging); the pixel coordinates of its EB rows are carried
+  // from K-tile to K-tile (no divisions in the loop)
   int cv_c = 0, cv_dy = 0, cv_dx = 0;
   bool cv_ok = false;
-  const int HW = p.H * p.W;
+  int cv_b[CONVB ? EB : 1], cv_y[CONVB ? EB : 1], cv_x[CONVB ? EB : 1];
   if (CONVB) {
+    const int HW = p.H * p.W;
     const int gn = n0 + bn;
     cv_ok = gn < p.N;
     const int tap = cv_ok ? gn / p.conv_C : 0;
     cv_c = gn - tap * p.conv_C;
     cv_dy = tap / 3 - 1;
     cv_dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+    for (int i = 0; i < EB; ++i) {
+      const int gk = kb + bk + i * bkstep;
+      cv_b[i] = gk / HW;
+      const int rem = gk - cv_b[i] * HW;
+      cv_y[i] = rem / p.W;
+      cv_x[i] = rem - cv_y[i] * p.W;
+    }
   }
 
   tg_f32x16 acc[TM][TN];
@@ -88,11 +98,12 @@ __global__ __launch_bounds__(256) void tgemm_kernel(const TGemmArgs p, const int
       float v = 0.f;
       if (CONVB) {
         if (cv_ok && gk < ke) {
-          const int b = gk / HW, rem = gk - b * HW;
-          const int y = rem / p.W, x = rem - y * p.W;
-          const int sy = y + cv_dy, sx = x + cv_dx;
-          if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) v = B[((long)(b * p.H + sy) * p.W + sx) * p.ldx + cv_c];
+          const int sy = cv_y[i] + cv_dy, sx = cv_x[i] + cv_dx;
+          if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) v = B[((long)(cv_b[i] * p.H + sy) * p.W + sx) * p.ldx + cv_c];
         }
+        cv_x[i] += BK;                      // the row this slot stages in the next K-tile
+        while (cv_x[i] >= p.W) { cv_x[i] -= p.W; ++cv_y[i]; }
+        while (cv_y[i] >= p.H) { cv_y[i] -= p.H; ++cv_b[i]; }
       } else if (gn < p.N && gk < ke) {
         v = B[(long)gk * p.sBk + (long)gn * p.sBn];
       }
@@ -164,7 +175,9 @@ int launch_tgemm(const TGemmArgs& a, hipStream_t s) {
                             "tgemm: convolution gather shapes");
   const long nz = (long)a.nz0 * a.nz1;
   T2P_REQUIRE(nz <= 65535, "tgemm: batch count");
-  const bool big = a.M >= 128 && a.N >= 128 && (long)cdiv_l(a.M, 128) * cdiv_l(a.N, 128) * nz >= 128;
+  // 128 x 128 tiles when they fill the chip by themselves -- or together with the K splits this call may choose (weight gradients)
+  const long tiles128 = (long)cdiv_l(a.M, 128) * cdiv_l(a.N, 128) * nz;
+  const bool big = a.M >= 128 && a.N >= 128 && (tiles128 >= 128 || (a.ksplit == 0 && tiles128 * (a.K / 256) >= 128));
   const int bt = big ? 128 : 64;
   int ksplit = a.ksplit;
   if (ksplit == 0) {
