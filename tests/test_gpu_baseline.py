@@ -178,19 +178,30 @@ F32_RUN1000_TOL = 1e-5   # 2000 chained fp32 evaluations against the reference's
                          # differences of ~1e-6 per evaluation compound over the run (measured values: gpurun_out/r03_parity.json)
 
 
-@pytest.mark.parametrize("stem", ["cond_length", "test_config"])
+RUN1000_YAML = {"cond_length": "cond_length.yml", "test_config": "test_config.yml", "cond_length_inpainting": "cond_length_inpainting.yml",
+                "test_config_L128": "test_config.yml"}
+
+
+@pytest.mark.parametrize("stem", ["cond_length", "test_config", "cond_length_inpainting", "test_config_L128"])
 def test_thousand_step_run_vs_reference(stem):
     """The horizon the metric is quoted on, pinned by the REFERENCE: complete N = 1000 runs of the reference sampler
-    (tests/golden/make_golden_full.py, run1000_<stem>.npz) on counter-based noise, B = 2 -- cond_length.yml at L = 128 with the
-    length condition (a shard of BASELINE configs[2]) and test_config.yml at L = 64.  The f16 engine (the benchmarked
-    precision) must end within the north star's 1e-3 of the reference's final samples."""
+    (tests/golden/make_golden_full.py, run1000_<stem>.npz) on counter-based noise -- cond_length.yml at L = 128 with the length
+    condition (B = 2: a shard of BASELINE configs[2]), test_config.yml at L = 64 (B = 2) and, since round 4, cond_length_inpainting.yml
+    (C = 8, length 100 + inpainting "1:5,10:15" on synthetic coords_6d: a shard of configs[4]) and test_config.yml at the benchmark's own
+    L = 128 (B = 1: configs[1]).  The f16 engine (the benchmarked precision) must end within the north star's 1e-3 of the reference's
+    final samples."""
     from text2protein_amd import sampling, sde_lib, synth
+    from text2protein_amd.conditions import pair_mask, parse_mask_info
     from text2protein_amd.config import load_config
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", f"run1000_{stem}.npz")):
+        pytest.skip(f"run1000_{stem}.npz has not been generated yet (tests/golden/make_golden_full.py --only run1000_{stem})")
     g = load_golden("run1000_" + stem)
     B, L, N, T, length = int(g["B"]), int(g["L"]), int(g["N"]), int(g["T"]), int(g["length"])
+    mask_info = str(g["mask_info"]) if "mask_info" in g else ""
     assert N == 1000
-    cfg = load_config(os.path.join(ROOT, "configs", FULL[stem][0]), **{"data.max_res_num": L, "model.num_scales": N})
+    cfg = load_config(os.path.join(ROOT, "configs", RUN1000_YAML[stem]), **{"data.max_res_num": L, "model.num_scales": N})
     cfg.device = "cuda:0"
+    C = cfg.data.num_channels
     sd = synth.synth_state_dict(cfg, 0)
     ctx = synth.synth_context(B, T, cfg.model.context_dim, int(g["context_seed"]))
     cond = {}
@@ -198,12 +209,15 @@ def test_thousand_step_run_vs_reference(stem):
         m = torch.zeros(B, L, L).bool()
         m[:, :length, :length] = True
         cond["length"] = m.cuda()
+    if mask_info:
+        coords = torch.from_numpy(synth.uniform_pm1(int(g["coords_seed"]), "coords_6d", B * C * L * L).reshape(B, C, L, L))
+        cond["inpainting"] = {"coords_6d": coords.cuda(), "mask_inpaint": pair_mask(parse_mask_info(mask_info, B, L)).cuda()}
     sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=N)
-    fn = sampling.get_sampling_fn(cfg, sde, (B, cfg.data.num_channels, L, L), 1e-5)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, C, L, L), 1e-5)
     res = {}
-    # the exact-f32 engine's 1000-step figure is taken on the cond_length fixture; on test_config (2.0e-6, profiles/r03_parity.json) it
-    # costs a minute of the GPU box's time limit and runs only with T2P_LONG_TESTS=1
-    dts = ("f32", "f16") if stem == "cond_length" or os.environ.get("T2P_LONG_TESTS") == "1" else ("f16",)
+    # the exact-f32 engine's 1000-step figure is taken on the two cond_length fixtures; on test_config (2.0e-6, profiles/r03_parity.json) it
+    # costs a minute or more of the GPU box's time limit and runs only with T2P_LONG_TESTS=1
+    dts = ("f32", "f16") if stem.startswith("cond_length") or os.environ.get("T2P_LONG_TESTS") == "1" else ("f16",)
     for dt in dts:
         m = _model(cfg, sd, dt)
         noise = CounterNoise(int(g["noise_seed"]))
@@ -212,6 +226,10 @@ def test_thousand_step_run_vs_reference(stem):
         assert nfe == int(g["nfe"]) == 2 * N and noise.k == 1 + 2 * N
         res[dt] = rel_l2(out.cpu(), g["sample"])
         print(f"{stem}: 1000 PC steps, {dt} final sample vs the REFERENCE's run: rel-L2 = {res[dt]:.3e}")
+        if mask_info:      # the known region (outside the inpainted rows / columns, inside the length mask) is coords_6d exactly
+            known = (~cond["inpainting"]["mask_inpaint"]).unsqueeze(1).expand(B, C, L, L).clone()
+            known[:, -1] = False
+            assert torch.equal(out[known], cond["inpainting"]["coords_6d"][known])
         del m
     _record(f"run1000_vs_reference_{stem}", res)
     assert res.get("f32", 0.0) < F32_RUN1000_TOL and res["f16"] < F16_TOL
