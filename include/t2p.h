@@ -69,7 +69,10 @@ int t2p_engine_finalize(t2p_engine* e);
 /* context: device fp32 [batch][tokens][context_dim] */
 int t2p_engine_set_context(t2p_engine* e, const float* context, int batch, int tokens, void* stream);
 /* x: device fp32 (batch, C, L, L); labels: device int32 [batch] time labels (index into the
- * descending sigma table); out: device fp32 (batch, C, L, L) = network output / sigma[label]. */
+ * descending sigma table); out: device fp32 (batch, C, L, L) = network output / sigma[label].
+ * Range precondition of the 16-bit engines: with sigma_max <= 4096 the input convolution runs on f16 operand pairs and needs
+ * |x| <= 65504 (a VE state stays within a few sigma_max); larger magnitudes saturate to that bound -- finite but wrong -- rather
+ * than producing inf / NaN.  The f32 engine has no such bound. */
 int t2p_engine_score(t2p_engine* e, const float* x, const int32_t* labels, float* out, int batch, void* stream);
 /* as t2p_engine_score, with optional fractional time values for the sinusoidal embedding: the VP
  * branch of get_score_fn passes labels = t * (N - 1) as floats (models/utils.py:150-152); the

@@ -323,6 +323,9 @@ def test_measurement_hooks_count_and_time_what_runs():
     x = sampling._device_randn_like(torch.empty(2, 5, 16, 16, device="cuda"), 9, 0) * 100.0
     xm = torch.empty_like(x)
     st.reset(0)
+    from text2protein_amd._lib import T2PError
+    with pytest.raises(T2PError, match="eager step"):    # capturing the very first step would record, not run, the one-off weight copies
+        st.count_dispatches(x, xm)
     st.step(x, xm)                                       # fills the activation pool
     torch.cuda.synchronize()
     before = x.clone()

@@ -27,6 +27,19 @@ def _hipcc():
 
 STAMP = LIB + ".srchash"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+_COMPILER_ID = None
+
+
+def compiler_id() -> str:
+    """Version text of the compiler that would build the library: part of every hash, so objects of another ROCm release are
+    never linked or loaded as if they were current.  Empty when no hipcc is installed (a box that only loads the prebuilt library)."""
+    global _COMPILER_ID
+    if _COMPILER_ID is None:
+        try:
+            _COMPILER_ID = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout.strip()
+        except (OSError, RuntimeError, subprocess.SubprocessError):
+            _COMPILER_ID = ""
+    return _COMPILER_ID
 
 
 def source_hash(ablation: bool = False) -> str:
@@ -34,6 +47,7 @@ def source_hash(ablation: bool = False) -> str:
     (File times do not survive the copy to the GPU box; contents do.)"""
     h = hashlib.sha256()
     h.update(" ".join(FLAGS + (["-DT2P_ABLATION"] if ablation else [])).encode())
+    h.update(compiler_id().encode())
     for f in SOURCES + HEADERS:
         h.update(f.encode())
         with open(os.path.join(CSRC, f), "rb") as fh:
@@ -45,6 +59,7 @@ def unit_hash(src: str, flags) -> str:
     """Identity of one object file: its source, every header and the flags (unchanged units are not recompiled)."""
     h = hashlib.sha256()
     h.update(" ".join(flags).encode())
+    h.update(compiler_id().encode())
     seen, todo = [], [os.path.join(CSRC, src)]
     while todo:                                   # the source and the local headers it includes, transitively
         f = os.path.normpath(todo.pop())

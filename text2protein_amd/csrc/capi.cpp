@@ -687,6 +687,7 @@ int t2p_profile_layers_end(char* buf, int len) {
   T2P_REQUIRE(buf && len > 0, "null argument");
   std::string out;
   T2P_TRY(t2p::layer_profile_end(&out));
+  T2P_REQUIRE((size_t)len > out.size(), "the per-block timing table does not fit the buffer (" + std::to_string(out.size() + 1) + " bytes needed)");
   std::snprintf(buf, (size_t)len, "%s", out.c_str());
   return T2P_OK;
   API_END

@@ -56,7 +56,9 @@ void debug_tap_shape(long out[4]) { for (int i = 0; i < 4; ++i) out[i] = g_tap_s
 struct LayerRec { std::string label; hipEvent_t e0, e1; };
 static bool g_layer_prof = false;
 static std::vector<LayerRec> g_layer_recs;
+static std::mutex g_layer_mu;      // the records are process-global (a measurement hook): engines on other threads append under the lock
 void layer_profile_begin() {
+  std::lock_guard<std::mutex> lk(g_layer_mu);
   for (LayerRec& r : g_layer_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   g_layer_recs.clear();
   g_layer_prof = true;
@@ -69,15 +71,21 @@ struct LayerScope {
     LayerRec r; r.label = label;
     if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
     (void)hipEventRecord(r.e0, s);
+    std::lock_guard<std::mutex> lk(g_layer_mu);
     idx = (int)g_layer_recs.size();
     g_layer_recs.push_back(r);
   }
-  ~LayerScope() { if (idx >= 0) (void)hipEventRecord(g_layer_recs[idx].e1, s); }
+  ~LayerScope() {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_layer_mu);
+    if (idx < (int)g_layer_recs.size()) (void)hipEventRecord(g_layer_recs[idx].e1, s);
+  }
 };
 // CSV "label,ms" per record, in launch order
 int layer_profile_end(std::string* out) {
   g_layer_prof = false;
   T2P_HIP_CHECK(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> lk(g_layer_mu);
   out->clear();
   for (LayerRec& r : g_layer_recs) {
     float ms = 0.f;
@@ -862,11 +870,17 @@ int Engine::res_block(Layer& L, const Act& x, const Act* skip, Act* out, int B, 
       if (g_small_conv_fm && c0.ldw % 32 == 0 && c1.ldw % 32 == 0) {
         // fragment-major weight copies (whole cache lines per fragment load), made the first time the block takes this path
         if (!L.fm_conv0) {
-          L.fm_conv0 = pool_.persistent((size_t)Cout * c0.ldw * 2);
-          L.fm_conv1 = pool_.persistent((size_t)Cout * c1.ldw * 2);
-          if (!L.fm_conv0 || !L.fm_conv1) return T2P_ERR_HIP;
-          T2P_TRY(launch_sf_frag_major(dt, c0.Wt, L.fm_conv0, Cout, (int)c0.ldw, s));
-          T2P_TRY(launch_sf_frag_major(dt, c1.Wt, L.fm_conv1, Cout, (int)c1.ldw, s));
+          // never under a stream capture (the conversions would be recorded, not run, and the copies stay uninitialised: every later
+          // evaluation would read garbage weights); the pointers are published only after both copies have been enqueued
+          hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+          if (s) (void)hipStreamIsCapturing(s, &cap);
+          T2P_REQUIRE(cap == hipStreamCaptureStatusNone, "the first evaluation builds per-block weight copies: run one eager step before capturing");
+          void* f0 = pool_.persistent((size_t)Cout * c0.ldw * 2);
+          void* f1 = pool_.persistent((size_t)Cout * c1.ldw * 2);
+          if (!f0 || !f1) return T2P_ERR_HIP;
+          T2P_TRY(launch_sf_frag_major(dt, c0.Wt, f0, Cout, (int)c0.ldw, s));
+          T2P_TRY(launch_sf_frag_major(dt, c1.Wt, f1, Cout, (int)c1.ldw, s));
+          L.fm_conv0 = f0; L.fm_conv1 = f1;
         }
         c0.Wt = L.fm_conv0; c0.w_fm = 1; c1.Wt = L.fm_conv1; c1.w_fm = 1;
       }
@@ -1433,8 +1447,11 @@ int Engine::run_stage(Stage& st, Act& h, const Act* skip, int B, hipStream_t s, 
     if (g_tap_index >= 0 && g_tap_counter++ == g_tap_index) {
       const long n = (long)B * nxt.H * nxt.W * nxt.C;
       g_tap_shape[0] = nxt.C; g_tap_shape[1] = nxt.H; g_tap_shape[2] = nxt.W; g_tap_shape[3] = nxt.lowp;
-      T2P_REQUIRE(g_tap_dst && n <= g_tap_cap, "tap buffer too small");
-      T2P_TRY(launch_widen(nxt.p, nxt.lowp ? dtype() : DT_F32, g_tap_dst, n, s));
+      float* dst = g_tap_dst;
+      const long cap = g_tap_cap;
+      g_tap_index = -1; g_tap_dst = nullptr; g_tap_cap = 0;      // one capture per arming: a later evaluation never writes to a buffer the caller may have freed
+      T2P_REQUIRE(dst && n <= cap, "tap buffer too small");
+      T2P_TRY(launch_widen(nxt.p, nxt.lowp ? dtype() : DT_F32, dst, n, s));
     }
     drop_pre_norm(cur);              // (only if this layer did not take it)
     if (own) free_act(cur);
@@ -1701,6 +1718,11 @@ int Sampler::step(float* x, float* x_mean, const float* nc, const float* np, hip
   // Langevin batch mean over global_batch chains (reference DataParallel run): needs the norm sums of the other
   // processes, i.e. the all-reduce hook; without it the mean runs over this process's chains
   T2P_REQUIRE(cfg_.global_batch == cfg_.batch || allreduce_, "global_batch > batch needs t2p_sampler_set_norm_allreduce");
+  {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s) (void)hipStreamIsCapturing(s, &cap);
+    if (cap == hipStreamCaptureStatusNone && eager_steps_ < (1 << 30)) ++eager_steps_;     // steps that really ran (step_graph / count_dispatches ask)
+  }
   const int B = cfg_.batch;
   const bool vp = cfg_.sde == T2P_SDE_VP;
   T2P_REQUIRE(!vp || vp_label_f_, "VP SDE: call t2p_sampler_set_vp_tables first");
@@ -1751,10 +1773,8 @@ int Sampler::step_graph(float* x, float* x_mean, hipStream_t s) {
   T2P_REQUIRE(x && x_mean, "step_graph needs explicit x and x_mean buffers");
   T2P_REQUIRE(!allreduce_, "the captured step does not run the norm all-reduce hook: use t2p_sampler_step");
   T2P_REQUIRE(host_step_ >= 0 && host_step_ < cfg_.N, "PC step index beyond sde.N: call t2p_sampler_reset before another run");
-  if (eager_steps_ < 1) {            // one eager step first: fills the activation pool (no hipMalloc under capture)
-    ++eager_steps_;
+  if (eager_steps_ < 1)              // one eager step first: fills the activation pool (no hipMalloc under capture); step() counts it
     return step(x, x_mean, nullptr, nullptr, s);
-  }
   if (graph_exec_ && (graph_x_ != x || graph_xm_ != x_mean || graph_mask_ != mask_ || graph_seed_ != cfg_.seed)) {
     (void)hipGraphExecDestroy(graph_exec_);
     graph_exec_ = nullptr;
@@ -1784,6 +1804,7 @@ int Sampler::step_graph(float* x, float* x_mean, hipStream_t s) {
 // are counted.  Needs a non-default stream and a filled activation pool (one eager step before).
 int Sampler::count_dispatches(float* x, float* x_mean, hipStream_t s, int* n_out) {
   T2P_REQUIRE(x && x_mean && n_out, "null argument");
+  T2P_REQUIRE(eager_steps_ >= 1, "count_dispatches captures a step: run one eager step first (it sizes the pool and builds per-block weight copies)");
   T2P_REQUIRE(!allreduce_, "the captured step does not run the norm all-reduce hook");
   T2P_REQUIRE(host_step_ >= 0 && host_step_ < cfg_.N, "PC step index beyond sde.N: call t2p_sampler_reset before another run");
   hipGraph_t graph = nullptr;

@@ -1052,6 +1052,7 @@ __device__ __forceinline__ float prow16_sum(float x) {        // sum over the 16
   return x;
 }
 __host__ __device__ inline void split_f16(float v, _Float16& hi, _Float16& lo) {
+  v = fminf(fmaxf(v, -65504.f), 65504.f);      // outside the f16 range the operand saturates (finite, wrong) instead of turning the output into inf / NaN
   hi = fabsf(v) < 6.103515625e-05f ? (_Float16)0.f : (_Float16)v;
   lo = (_Float16)((v - (float)hi) * 2048.f);
 }

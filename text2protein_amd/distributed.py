@@ -50,7 +50,7 @@ def launch_local(n_ranks: int, argv, env_extra=None, timeout=None, poll_s=0.2) -
     """Start ``n_ranks`` fresh child interpreters running ``argv`` (a script path + its arguments), one rank per
     GPU of this node, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way
     ``torch.distributed.run`` sets them; returns the exit code of the job: 0 when every rank succeeded, otherwise the
-    code of the FIRST rank seen failing (signals as positive numbers).
+    code of the lowest-numbered rank found failed at that poll (signals as positive numbers).
 
     The ranks are watched together: as soon as one exits non-zero the others are terminated (they would otherwise sit in
     ``init_process_group`` / a barrier / the gather until the collective's own 10-30 minute timeout, holding every GPU).
