@@ -30,8 +30,11 @@ The JSON line (rank 0), beyond the contract's keys:
                             arithmetic type): --f32-steps (10) steps after a warm-up step, with its own kernel roofline
                             against the 157.3 TFLOP/s f32 matrix peak
   cpu_baseline              N = 1: the oracle on the host cores, 2 chains x 3 PC steps after one warm-up step, scaled by N
-  cfg3                      N > 1: BASELINE configs[2] (cond_length.yml, 32 chains per GPU, length condition) measured by the same
-                            ranks with the same bracketing -- the workload the north star's 1000 samples/min is about
+  cfg3, cfg5                N > 1: BASELINE configs[2] (cond_length.yml, 32 chains per GPU, length condition: the workload the north
+                            star's 1000 samples/min is about) and configs[4] (cond_length_inpainting.yml, 16 chains per GPU, length +
+                            inpainting) measured by the same ranks with the same bracketing
+  per_rank_ms_per_step      every rank's OWN device time per PC step (HIP events around its steps, all-gathered after the timed
+                            region), in rank order, next to the max-over-ranks wall time `ms_per_step` is computed from
 """
 import argparse
 import ctypes as C
@@ -76,7 +79,7 @@ def parse():
     ap.add_argument("--layers", default="", help="write the per-block times of one PC step (HIP events at block boundaries, CSV) to this file")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 engine's line (rank 0, N = 1)")
     ap.add_argument("--f32-steps", type=int, default=10)
-    ap.add_argument("--no-cfg3", action="store_true", help="with --gpus N > 1: skip the additional cfg3 (BASELINE configs[2]) measurement")
+    ap.add_argument("--no-cfg3", action="store_true", help="with --gpus N > 1: skip the additional cfg3 / cfg5 (BASELINE configs[2] / configs[4]) measurements")
     return ap.parse_args()
 
 
@@ -180,16 +183,22 @@ class Job:
         # the schedule tables hold N steps: the timed region starts at step 0 of a run and rewinds every N steps
         rewind()
         D.barrier(dist, dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        ev0.record()
         for i in range(steps):
             if i and i % self.N == 0:
                 rewind()
             run_step(x, xm)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
+        ev1.record()                                         # this rank's own steps end here (device time, no host wait added)
         gathered = D.gather_samples(xm, dist)                # the single collective of a run (no-op at N = 1)
         D.barrier(dist, dev)
         dt = D.max_over_ranks(time.perf_counter() - t0, dist, dev)
+        # every rank's OWN device time per step, gathered after the region: a short scaling curve can then be read as "the code"
+        # (all ranks slow) or "one slow device" (the timed region ends at the slowest rank)
+        self.per_rank_ms = D.all_ranks(ev0.elapsed_time(ev1) / steps, dist, dev)
         world = dist.get_world_size() if dist is not None else 1
         finite = bool(torch.isfinite(gathered).all().item()) and gathered.shape[0] == self.B * world
         return dt, finite
@@ -297,6 +306,7 @@ def main():
         # roofline.traffic is NOT measured by this run: it is the HBM byte count of the committed rocprofv3 --pmc passes of this
         # same command (profiles/), see roofline.traffic_from_profile
         "traffic_measured_in_run": False,
+        "per_rank_ms_per_step": job.per_rank_ms,
     }
     if rank == 0 and not args.graph:
         job.stepper.reset(0)
@@ -315,14 +325,17 @@ def main():
                 r["traffic_from_profile"] = {"bytes_per_launch": r["traffic"], "file": os.path.relpath(tfile[-1], ROOT)}
         out["roofline"] = r
     if world > 1 and args.workload == "cfg2" and not args.no_cfg3:
-        # BASELINE.json configs[2] (cond_length.yml, 32 chains per GPU, length condition): the workload the north star's
-        # ">= 1000 samples/min on 8 GPUs" is about, measured by the same ranks with the same bracketing; cfg2 stays the headline
-        job3 = Job("cfg3", args.dtype, dev, rank)
-        dt3, fin3 = job3.timed(args.steps, args.warmup, dist, 0)
-        v3 = job3.B * world / (job3.N * dt3 / args.steps)
-        out["cfg3"] = {"value": v3, "unit": "samples/s", "samples_per_min": v3 * 60.0, "ms_per_step": dt3 / args.steps * 1e3,
-                       "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "finite": fin3, "workload": job3.describe()}
-        del job3
+        # BASELINE.json configs[2] (cond_length.yml, 32 chains per GPU, length condition: the workload the north star's
+        # ">= 1000 samples/min on 8 GPUs" is about) and configs[4] (cond_length_inpainting.yml, 16 chains per GPU, length + inpainting:
+        # the other 8-GPU configuration), measured by the same ranks with the same bracketing; cfg2 stays the headline
+        for name in ("cfg3", "cfg5"):
+            jobx = Job(name, args.dtype, dev, rank)
+            dtx, finx = jobx.timed(args.steps, args.warmup, dist, 0)
+            vx = jobx.B * world / (jobx.N * dtx / args.steps)
+            out[name] = {"value": vx, "unit": "samples/s", "samples_per_min": vx * 60.0, "ms_per_step": dtx / args.steps * 1e3,
+                         "per_rank_ms_per_step": jobx.per_rank_ms, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                         "finite": finx, "workload": jobx.describe()}
+            del jobx
     if rank == 0 and world == 1 and not args.no_f32 and args.dtype != "f32":
         # the same workload on the exact-f32 engine (v_mfma_f32_32x32x2_f32: the reference's own arithmetic type), timed over
         # the same kind of region, with its own kernel roofline against the 157.3 TFLOP/s f32 matrix peak

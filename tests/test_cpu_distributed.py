@@ -142,3 +142,65 @@ def test_launch_local_deadline_covers_the_whole_job():
     with pytest.raises(subprocess.TimeoutExpired):
         D.launch_local(2, ["-c", "import time; time.sleep(60)"], timeout=1.5)
     assert time.monotonic() - t0 < 15
+
+
+def _trampoline_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from text2protein_amd import distributed as D
+    from text2protein_amd import sampling
+    from text2protein_amd._lib import T2PError
+    dist = D.init_process_group(device="cpu")
+    sums = torch.tensor([1.0 + rank, 10.0 * (1 + rank)])
+    calls = []
+
+    def all_reduce(t):
+        calls.append(len(calls))
+        if len(calls) == 2 and rank == 1:
+            raise ConnectionError("xGMI link 3 went away (rank 1, corrector step 2)")
+        D.allreduce_norm_sums(t, dist)
+
+    cb, pending = sampling.allreduce_trampoline(all_reduce, sums)
+    # what t2p_sampler_step does with the hook (engine.cpp, Sampler::step): call it through the C function pointer; non-zero = fail the step
+    rc1 = cb(C.c_void_p(sums.data_ptr()), None, None)
+    first = sums.clone()
+    rc2 = cb(C.c_void_p(sums.data_ptr()), None, None) if rank == 1 else 0     # rank 0 is not in a collective here: rank 1 fails BEFORE it
+    text = None
+    try:
+        if rc2 != 0:
+            sampling.raise_allreduce_error(pending, T2PError("libt2p_hip call failed (status 1): all-reduce callback"))
+    except T2PError as e:
+        text = (str(e), type(e.__cause__).__name__, len(pending))
+    q.put((rank, rc1, first.tolist(), rc2, text))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_allreduce_trampoline_surfaces_the_callables_own_exception():
+    """Option B's hook (sampling.allreduce_trampoline, what PCStepper installs with t2p_sampler_set_norm_allreduce) on two gloo ranks:
+    the first call sums the two norm sums over the ranks; then rank 1's callable raises -- the C-side sees status 1, and the caller
+    gets a T2PError carrying the ORIGINAL exception's text with the exception itself as __cause__ (the advisor fix of round 3)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trampoline_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r = q.get(timeout=100)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        rc1, first, _, _ = got[rank]
+        assert rc1 == 0 and first == [3.0, 30.0]                     # summed over both ranks, in place
+    assert got[0][2] == 0 and got[0][3] is None
+    rc2, text = got[1][2], got[1][3]
+    assert rc2 == 1 and text is not None
+    assert "xGMI link 3 went away (rank 1, corrector step 2)" in text[0] and "norm all-reduce failed" in text[0]
+    assert text[1] == "ConnectionError" and text[2] == 0             # the cause is attached, nothing stays parked

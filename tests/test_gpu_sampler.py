@@ -358,3 +358,38 @@ def test_measurement_hooks_count_and_time_what_runs():
     out2 = model(x, labels, ctx)
     torch.cuda.synchronize()
     assert torch.equal(out, out2) and torch.equal(tap, snapshot)
+
+
+def test_norm_allreduce_hook_failure_reaches_the_caller_with_its_own_text():
+    """The option-B hook (t2p_sampler_set_norm_allreduce) whose Python callable raises: t2p_sampler_step must fail, and the caller must
+    see the callable's own exception (text and __cause__), not a bare status code; the stepper stays usable afterwards."""
+    from text2protein_amd import sampling, sde_lib, synth
+    from text2protein_amd._lib import T2PError
+    from text2protein_amd.model import HipScoreModel
+    cfg = cfg_tiny()
+    cfg.device = "cuda"
+    model = HipScoreModel(cfg, dtype="f32")
+    model.load_state_dict(synth.synth_state_dict(cfg, 0))
+    model.set_context(synth.synth_context(1, 3, cfg.model.context_dim, 0).cuda())
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=cfg.model.num_scales)
+    state = {"fail": True, "calls": 0}
+
+    def all_reduce(t):
+        state["calls"] += 1
+        if state["fail"]:
+            raise ConnectionError("rank 5 left the job")
+        t.mul_(2.0)                                   # stand-in for the sum over two identical ranks
+
+    st = sampling.PCStepper(model, sde, 1, cfg.sampling.snr, seed=3, global_batch=2, all_reduce=all_reduce)
+    x = sampling._device_randn_like(torch.empty(1, 5, 16, 16, device="cuda"), 4, 0) * 50.0
+    xm = torch.empty_like(x)
+    st.reset(0)
+    with pytest.raises(T2PError, match="rank 5 left the job") as ei:
+        st.step(x, xm)
+    assert isinstance(ei.value.__cause__, ConnectionError) and state["calls"] == 1
+    torch.cuda.synchronize()
+    state["fail"] = False
+    st.reset(0)
+    st.step(x, xm)
+    torch.cuda.synchronize()
+    assert torch.isfinite(x).all() and state["calls"] == 2

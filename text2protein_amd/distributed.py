@@ -122,6 +122,16 @@ def max_over_ranks(value: float, dist=None, device="cpu") -> float:
     return float(t.item())
 
 
+def all_ranks(value: float, dist=None, device="cpu"):
+    """Every rank's own figure, in rank order (one all_gather of a scalar): lets a scaling record separate the code from a slow device."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def chain_ids(chains_per_rank: int, rank: int):
     """Global ids of the chains a rank owns (rank-major, the order ``gather_samples`` returns)."""
     return list(range(rank * chains_per_rank, (rank + 1) * chains_per_rank))

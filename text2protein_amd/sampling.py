@@ -238,6 +238,33 @@ def shared_corrector_update_fn(x, t, context, sde, model, corrector, snr, n_step
 # ------------------------------------------------------------------------------------------------
 # the sampler
 # ------------------------------------------------------------------------------------------------
+def allreduce_trampoline(all_reduce, sums):
+    """The C-callable (``t2p_allreduce_fn``) the fused sampler calls once per corrector step, wrapping ``all_reduce(sums)``.
+    A Python exception must not unwind through the C frame: it is parked in the returned list and the callback returns 1, which
+    makes ``t2p_sampler_step`` fail; ``raise_allreduce_error`` then surfaces the ORIGINAL exception to the caller.  The closure
+    holds the list and the tensor, never the stepper (no reference cycle)."""
+    err = []
+
+    def _cb(_ptr, _stream, _user, _t=sums, _fn=all_reduce, _err=err):
+        try:
+            _fn(_t)                                # sums the caller-owned buffer the sampler just filled
+            return 0
+        except Exception as e:  # noqa: BLE001
+            _err.append(e)
+            return 1
+
+    return _lib.ALLREDUCE_FN(_cb), err
+
+
+def raise_allreduce_error(pending, fallback):
+    """Re-raise what the all-reduce callable raised (with its text and as ``__cause__``), or ``fallback`` when it did not."""
+    if pending:
+        cause = pending.pop()
+        pending.clear()
+        raise T2PError(f"the norm all-reduce failed: {cause!r}") from cause
+    raise fallback
+
+
 class PCStepper:
     """Handle on the fused C++ sampler (t2p_sampler_*): one ``step`` = one iteration of the loop
     body of the reference ``pc_sampler`` (sampling.py:279-285) enqueued on the current stream."""
@@ -286,17 +313,7 @@ class PCStepper:
         self.N = int(sde.N)
         if all_reduce is not None:
             self._sums = torch.zeros(2, device=model.device, dtype=torch.float32)
-            self._cb_error = err = []               # the trampoline's closure holds this list, not the stepper (no cycle)
-
-            def _cb(_ptr, _stream, _user, _t=self._sums, _fn=all_reduce, _err=err):
-                try:
-                    _fn(_t)                        # sums the caller-owned buffer the sampler just filled
-                    return 0
-                except Exception as e:  # noqa: BLE001  (must not unwind through the C frame)
-                    _err.append(e)
-                    return 1
-
-            self._cb = _lib.ALLREDUCE_FN(_cb)       # keep the trampoline alive as long as the sampler
+            self._cb, self._cb_error = allreduce_trampoline(all_reduce, self._sums)   # kept alive as long as the sampler
             check(self.lib.t2p_sampler_set_norm_allreduce(self._h, ptr(self._sums), self._cb, None))
 
     def set_seed(self, seed):
@@ -314,12 +331,7 @@ class PCStepper:
             check(self.lib.t2p_sampler_step(self._h, ptr(x), ptr(x_mean), ptr(noise_corrector), ptr(noise_predictor),
                                             stream_ptr()))
         except T2PError as e:
-            pending = getattr(self, "_cb_error", None)
-            if pending:                                # the all-reduce callable raised: surface ITS error
-                cause = pending.pop()
-                pending.clear()
-                raise T2PError(f"the norm all-reduce failed: {cause!r}") from cause
-            raise e
+            raise_allreduce_error(getattr(self, "_cb_error", None), e)
 
     def step_graph(self, x, x_mean):
         """One PC step replayed from a captured hipGraph (device noise; needs a non-default stream)."""
