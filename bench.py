@@ -70,8 +70,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="chains per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("T2P_GRAPH", "0")),
-                    help="replay each PC step from a captured hipGraph instead of launching its kernels one by one")
+    ap.add_argument("--graph", type=int, default=0, help="measurement only (tools/r04_graph_gaps.sh): replay each PC step from a captured "
+                    "hipGraph; slower than eager launches at every workload (DESIGN.md section 8), never the benchmark's mode")
     ap.add_argument("--plan", default="", help="A/B measurements: 'key=value,...' plan switches of t2p_debug_set "
                     "(include/t2p.h: tile geometry, split-K, individual fusions; all produce correct results)")
     ap.add_argument("--lib", default="", help="A/B measurements: load this libt2p_hip.so (built from another revision)")

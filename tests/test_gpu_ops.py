@@ -275,9 +275,9 @@ def test_philox_normal_moments(lib):
     assert torch.equal(out, out3)                                     # counter-based: reproducible
 
 
-@pytest.mark.parametrize("geom,ring", [(1, 1), (2, 1), (3, 1), (3, 0), (3, 2), (0, 1), (0, 2)])
+@pytest.mark.parametrize("geom,ring", [(1, 1), (2, 1), (3, 1), (3, 2), (0, 1), (0, 2)])
 def test_dma_kernel_variants_agree(lib, geom, ring):
-    """Every LDS-DMA geometry (256x128x3, 128x128x2, 256x256 with 2+2 / 3+2 rings and with the 16x16x32
+    """Every LDS-DMA geometry (256x128x3, 128x128x2, 256x256 with the 32x32x16 and with the 16x16x32
     MFMA shape) forced on the same operands: conv with halo + up-sampling, ragged M / N GEMM."""
     try:
         check(lib, lib.t2p_debug_set(2, geom))
@@ -309,44 +309,6 @@ def test_dma_kernel_variants_agree(lib, geom, ring):
     finally:
         lib.t2p_debug_set(2, 0)
         lib.t2p_debug_set(8, 2)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("geom", [3, 4])
-def test_conv_halo_kernel(lib, geom):
-    """3x3 convolution with the input halo resident in LDS (conv_halo_kernel; forced 256 x 256 / 512 x 128 tiles so that
-    small maps select it): maps of 16 .. 128 pixels per row incl. a width that is not a power of two, tiles that are a
-    whole sample / several image rows / a fraction of an image row pair, first and last tiles of a sample (zero rows
-    above and below), Cout not a multiple of the tile; exact products, so only the fp32 summation order differs from
-    the reference, and the implicit-GEMM kernel (halo switched off) must agree to the same level."""
-    try:
-        check(lib, lib.t2p_debug_set(2, geom))
-        g = torch.Generator().manual_seed(geom)
-        shapes = [(3, 16, 16, 64, 256), (2, 16, 32, 128, 128), (1, 32, 48, 64, 192), (2, 8, 64, 192, 256), (1, 8, 128, 64, 320),
-                  (2, 64, 64, 64, 128)]
-        for dt in (1, 2):
-            td = TDT[dt]
-            for (B, H, W, Cin, Cout) in shapes:
-                x = torch.randn(B, Cin, H, W, generator=g).to(td)
-                w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(td)
-                b = torch.randn(Cout, generator=g)
-                ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
-                outs = []
-                for halo in (1, 0):
-                    check(lib, lib.t2p_debug_set(16, halo))
-                    out = torch.full((B, H, W, Cout), float("nan"), device="cuda")
-                    check(lib, lib.t2p_op_conv3x3(dt, P(dev(x.permute(0, 2, 3, 1))), 0, P(dev(w.permute(0, 2, 3, 1))), P(dev(b)), P(out),
-                                                  B, H, W, Cin, Cout, 0, None))
-                    torch.cuda.synchronize()
-                    outs.append(out.cpu())
-                e = rel_l2(outs[0], ref)
-                assert e < 3e-6, (geom, dt, B, H, W, Cin, Cout, e)
-                assert rel_l2(outs[0], outs[1]) < 3e-6
-                if (H * W) % (256 if geom == 3 else 512) == 0:
-                    assert not torch.equal(outs[0], outs[1]), "the halo kernel did not run"     # another summation order
-    finally:
-        lib.t2p_debug_set(2, 0)
-        lib.t2p_debug_set(16, 1)
 
 
 @pytest.mark.gpu
@@ -533,8 +495,7 @@ def test_input_conv_and_its_column_statistics(lib, C, nf, H, W):
 @pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("B,n,mode", [(3, 256, "entry"), (2, 64, "entry"), (5, 32, "normed"), (32, 256, "entry"), (1, 1024, "normed"),
                                       (3, 256, "mid"), (32, 256, "mid"), (4, 64, "mid"), (32, 16, "mid"), (32, 16, "normed"), (3, 256, "tail"), (32, 256, "tail"),
-                                      (3, 256, "tail3"), (32, 256, "tail3"), (6, 64, "tail3"),
-                                      (3, 256, "entry512"), (32, 256, "entry512"), (5, 32, "normed512"), (8, 64, "mid512"), (32, 256, "mid512")])
+                                      (3, 256, "tail3"), (32, 256, "tail3"), (6, 64, "tail3")])
 def test_spatial_transformer_row_chain(lib, dt, B, n, mode):
     """t2p_op_st_entry: the row-wise chains of a SpatialTransformer block in one launch over 32-row blocks, against the same chain
     in fp64 with the intermediate roundings of the separate launches (a, t, LayerNorm(t) stored in the compute dtype).
@@ -543,9 +504,7 @@ def test_spatial_transformer_row_chain(lib, dt, B, n, mode):
     tail: t += to_out(o) + b -> LayerNorm_3 -> ff.net.0 with the GEGLU epilogue (rows interleaved (value, gate), :37-64, 214);
     tail3: the same followed by y = [g | t] W_3^T + b_3 + x (ff.net.2 and proj_out as one matrix, :213-215, 259-263) and the per-64-row
     column sums of y (accumulated by pairs of workgroups)."""
-    C, G = 256, 32
-    if mode.endswith("512"):          # the channel count of test_config's attention levels (entry and mid chains only)
-        C, mode = 512, mode[:-3]
+    C, G = 256, 32                    # (the C = 512 instantiation was removed in round 4: equal to the separate launches, twice)
     td = TDT[dt]
     g = torch.Generator().manual_seed(17 * n + B + len(mode) + C)
     x = (torch.randn(B, n, C, generator=g) * 1.5 + 0.3 * torch.randn(B, 1, C, generator=g)).to(td)

@@ -579,7 +579,6 @@ int t2p_debug_set(int key, int value) {
   if (key == 13) { g_gn_small = value != 0; return T2P_OK; }
   if (key == 14) { g_lowp_residual = value != 0; return T2P_OK; }
   if (key == 15) { set_gemm_thin_conv(value != 0); return T2P_OK; }
-  if (key == 16) { set_gemm_conv_halo(value != 0); return T2P_OK; }
   if (key == 17) { g_gn_apply16 = value != 0; return T2P_OK; }
   if (key == 20) { g_layernorm16 = value != 0; return T2P_OK; }
   if (key == 21) { set_gemm_up4(value != 0); return T2P_OK; }
@@ -597,7 +596,6 @@ int t2p_debug_set(int key, int value) {
   if (key == 41) { t2p::g_small_conv_fm = value != 0; return T2P_OK; }
   if (key == 42) { t2p::g_st_ffpo = value != 0; return T2P_OK; }
   if (key == 43) { t2p::g_st_tail_rows = value; return T2P_OK; }
-  if (key == 44) { t2p::g_st_fuse_512 = value != 0; return T2P_OK; }
   if (key == 45) { t2p::g_attn_fm = value != 0; return T2P_OK; }
   if (key == 46) { t2p::g_attn_proj = value != 0; return T2P_OK; }
   if (key == 34) { set_gemm_a_norm(value != 0); return T2P_OK; }

@@ -629,9 +629,8 @@ int Engine::finalize() {
         l.ff1.K = ci;
       }
       T2P_TRY(upload_linear(t + ".ff.net.2.weight", t + ".ff.net.2.bias", ci, 4 * ci, &l.ff2));
-      // (C = 512: the kernel exists and is tested, but its chains stream 4x the bytes per workgroup: cfg2 51.50 -> 51.50 ms per step
-      // with 100 dispatches fewer, cfg4 equal: taken only with plan switch 44)
-      if (cfg_.compute_dtype != DT_F32 && (ci == 256 || (ci == 512 && g_st_fuse_512)) && l.a1_qkv.w) {
+      // (C = 512: the chains stream 4x the bytes per workgroup and measured equal to the separate launches: not built)
+      if (cfg_.compute_dtype != DT_F32 && ci == 256 && l.a1_qkv.w) {
         // fragment-major copies of the row-chain kernel's weights (1 KiB contiguous per MFMA fragment)
         auto fm = [&](const void* w, int N, void** out) -> int {
           *out = pool_.persistent((size_t)N * ci * 2);
@@ -1242,7 +1241,6 @@ bool g_st_tail = true;
 int g_st_tail_rows = 4096;
 bool g_attn_proj = true;       // plan switch 46: the projections of an AttnBlockpp in one launch at C = 256 (attn_proj_kernel)
 bool g_attn_fm = true;         // plan switch 45: fragment-major K / V^T for the wide-head attention kernel (where the shapes allow it)
-bool g_st_fuse_512 = false;    // plan switch 44 (read when the engine is built): row chains at C = 512 too
 bool g_st_ffpo = true;         // plan switch 42: the merged ff.net.2 / proj_out product inside the chain after the cross-attention
 bool g_small_conv_fm = true;   // plan switch 41: the small-map convolution kernel reads fragment-major weight copies
 int Engine::st_block(Layer& L, const Act& x, Act* out, int B, hipStream_t s) {

@@ -578,8 +578,9 @@ int launch_attn_proj(const AttnProjArgs& a, hipStream_t s) {
 
 bool g_st_fuse = true;      // plan switch 39
 bool st_entry_eligible(const StEntryArgs& a) {
-  if (!g_st_fuse || (a.dtype != DT_F16 && a.dtype != DT_BF16) || (a.C != 256 && a.C != 512)) return false;
-  if (a.C == 512 && (a.geglu || a.w3)) return false;          // (the feed-forward chains stream 4x the bytes there: not built)
+  // C = 256 only.  (The C = 512 instantiation of round 3 -- A fragments re-read from LDS per column tile, two column tiles of weights in
+  // flight -- measured EQUAL to the separate launches at cfg2 and cfg4, twice, and was removed in round 4: DESIGN.md section 8.)
+  if (!g_st_fuse || (a.dtype != DT_F16 && a.dtype != DT_BF16) || a.C != 256) return false;
   // one round of workgroups (two rounds measured slower: cfg4's 32x32 level); a workgroup's 32 rows lie in one sample, except when
   // nothing per-sample is involved (no GroupNorm inside, no column sums out): then any split of the rows will do (4 x 4 maps)
   const bool per_sample = a.cstats || a.y_stats;
@@ -607,9 +608,7 @@ int launch_st_entry(const StEntryArgs& a, hipStream_t s) {
       hipLaunchKernelGGL(kern, grid, dim3(512), smem, s, a);                                                             \
     }                                                                                                                    \
   }
-  if (a.C == 512) {
-    if (a.n2 == 3 * a.C) T2P_SF(512, 12, false, false) else T2P_SF(512, 4, false, false)
-  } else if (a.w3) T2P_SF(256, 16, true, true) else if (a.geglu) T2P_SF(256, 16, true, false) else if (a.n2 == 3 * a.C) T2P_SF(256, 6, false, false)
+  if (a.w3) T2P_SF(256, 16, true, true) else if (a.geglu) T2P_SF(256, 16, true, false) else if (a.n2 == 3 * a.C) T2P_SF(256, 6, false, false)
   else T2P_SF(256, 2, false, false)
 #undef T2P_SF
   T2P_HIP_CHECK(hipGetLastError());

@@ -184,7 +184,6 @@ void set_gemm_force_nsplit(int v);
 void set_gemm_midsplit(bool on);
 void set_gemm_thin_conv(bool on);
 void set_gemm_a_norm(bool on);
-void set_gemm_conv_halo(bool on);
 void set_gemm_up4(bool on);
 void set_gemm_deep_ring(bool on);
 void set_gemm_fuse_shortcut(bool on);

@@ -217,7 +217,6 @@ extern bool g_st_fuse;
 extern bool g_small_conv_fm;   // engine.cpp (plan switch 41)
 extern bool g_attn_proj;       // engine.cpp (plan switch 46)
 extern bool g_attn_fm;         // engine.cpp (plan switch 45)
-extern bool g_st_fuse_512;     // engine.cpp (plan switch 44, read at engine build)
 extern int g_st_tail_rows;     // engine.cpp (development key 43)
 extern bool g_st_ffpo;         // engine.cpp (plan switch 42)
 extern bool g_st_tail;     // engine.cpp (plan switch 40)

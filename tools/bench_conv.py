@@ -28,7 +28,6 @@ def main():
     ap.add_argument("--no-dma", action="store_true")
     ap.add_argument("--c16", action="store_true", help="compute-dtype output instead of fp32")
     ap.add_argument("--nsplit", type=int, default=0, help="force this split-K factor (conv only; attaches a workspace)")
-    ap.add_argument("--halo", type=int, default=1, help="3x3 convolutions on the LDS-halo kernel where eligible (plan switch 16)")
     ap.add_argument("--plan", default="", help="further plan switches 'key=value,...' (t2p_debug_set)")
     ap.add_argument("--ablation", action="store_true", help="use the -DT2P_ABLATION library (needed for --dbg bits that skip work)")
     a = ap.parse_args()
@@ -39,7 +38,6 @@ def main():
     lib.t2p_debug_set(2, a.geom)
     lib.t2p_debug_set(8, a.ring)
     lib.t2p_debug_set(0, 0 if a.no_dma else 1)
-    lib.t2p_debug_set(16, a.halo)
     for kv in filter(None, a.plan.split(",")):
         k, v = kv.split("=")
         assert lib.t2p_debug_set(int(k), int(v)) == 0, kv
@@ -76,7 +74,7 @@ def main():
     ms = e0.elapsed_time(e1) / a.iters
     c16 = " c16" if a.c16 else ""
     fl = 2.0 * a.B * a.H * a.W * a.cout * a.taps * a.cin
-    print(f"{a.dtype} B{a.B} {a.H}x{a.W} cin{a.cin} cout{a.cout} taps{a.taps} dbg{a.dbg} geom{a.geom} ring{a.ring} nsplit{a.nsplit} halo{a.halo}{c16} plan[{a.plan}]: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s", flush=True)
+    print(f"{a.dtype} B{a.B} {a.H}x{a.W} cin{a.cin} cout{a.cout} taps{a.taps} dbg{a.dbg} geom{a.geom} ring{a.ring} nsplit{a.nsplit}{c16} plan[{a.plan}]: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":
