@@ -346,3 +346,69 @@ def test_trainer_refuses_what_it_does_not_cover():
         losses.HipTrainModel(cfg2, device="cuda:0")
     with pytest.raises(ValueError):
         losses.condition_flags(["length", "shape"])
+
+
+def test_training_checkpoint_round_trip_in_the_reference_layout(tmp_path):
+    """save_checkpoint / restore_training_state (score_sde_pytorch/utils.py:11-26): three steps, save, two more steps; a fresh model
+    restored from the file and stepped twice ends at the same parameters, EMA and moments.  The file is the reference's: torch's own
+    Adam accepts its optimizer entry, the sampling-side loader (checkpoint.restore_checkpoint) reads its EMA weights, and a
+    checkpoint WRITTEN BY THE REFERENCE (tests/golden/tiny_checkpoint.pth) restores into a training state."""
+    from text2protein_amd import checkpoint, losses, sde_lib, synth
+    from text2protein_amd.model import HipScoreModel
+    case = dict(TRAIN_CASES["train_tiny"], step0=4000)
+    cfg = case["config"]()
+    inp = train_inputs(cfg, case)
+    batch = {k: inp[k] for k in ("coords_6d", "mask_pair", "context")}
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=cfg.model.num_scales)
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg))
+
+    def new_state(seed_offset=0, step=4000):
+        m = _model_for(case, cfg, seed_offset)
+        return dict(model=m, optimizer=losses.get_optimizer(cfg, m.parameters()),
+                    ema=losses.ExponentialMovingAverage(m.parameters(), decay=cfg.model.ema_rate), step=step)
+
+    a = new_state()
+    for i in range(3):
+        step_fn(a, batch, condition=cfg.model.condition, t=inp["t"], z=torch.roll(inp["z"], i, 0))
+    path = str(tmp_path / "train_state.pth")
+    checkpoint.save_checkpoint(path, a)
+    for i in range(3, 5):
+        step_fn(a, batch, condition=cfg.model.condition, t=inp["t"], z=torch.roll(inp["z"], i, 0))
+    b = new_state(seed_offset=9, step=0)                       # other weights, other counters: everything must come from the file
+    checkpoint.restore_training_state(path, b)
+    assert b["step"] == 4003 and b["model"].get_step() == (4003, 3, 3)
+    for i in range(3, 5):
+        step_fn(b, batch, condition=cfg.model.condition, t=inp["t"], z=torch.roll(inp["z"], i, 0))
+    for which in (losses.PARAM, losses.EMA, losses.EXP_AVG, losses.EXP_AVG_SQ):
+        ta, tb = a["model"].read(which), b["model"].read(which)
+        # (fp32 atomics in the weight gradients: not bitwise; tensors whose gradient is zero in exact arithmetic hold noise: floor)
+        total = float(torch.sqrt(sum((v.double() ** 2).sum() for v in ta.values())))
+        worst = max(float((tb[n].double() - ta[n].double()).norm()) / max(float(ta[n].double().norm()), 3e-5 * total) for n in ta)
+        assert worst < 1e-4, (which, worst)
+    # the file itself
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"optimizer", "model", "ema", "step"} and ck["step"] == 4003
+    assert all(k.startswith("module.") for k in ck["model"]) and ck["model"]["module.sigmas"].dtype == torch.float64
+    shapes = [tuple(s) for _, s in a["model"].param_table()]
+    dummy = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    opt = torch.optim.Adam(dummy, lr=1e-4)
+    opt.load_state_dict(ck["optimizer"])                         # torch's own validation of the layout
+    assert int(opt.state[dummy[0]]["step"]) == 3 and opt.state[dummy[5]]["exp_avg"].shape == shapes[5]
+    assert ck["ema"]["num_updates"] == 3 and [tuple(t.shape) for t in ck["ema"]["shadow_params"]] == shapes
+    cfg.device = "cuda:0"
+    sm = HipScoreModel(cfg, dtype="f32")
+    assert checkpoint.restore_checkpoint(path, sm, cfg) == 4003   # the sampling driver's loader takes the EMA weights from it
+    # a checkpoint written by the reference's own save_checkpoint (DataParallel keys, empty Adam state, EMA shadow != live weights)
+    from helpers import cfg_ckpt
+    import os
+    cfg_r = cfg_ckpt()
+    cfg_r.model.dropout = 0.0
+    cfg_r.device = "cuda:0"
+    mr = losses.HipTrainModel(cfg_r, device="cuda:0")
+    st = dict(model=mr, optimizer=losses.get_optimizer(cfg_r, mr.parameters()),
+              ema=losses.ExponentialMovingAverage(mr.parameters(), decay=cfg_r.model.ema_rate), step=0)
+    checkpoint.restore_training_state(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_checkpoint.pth"), st)
+    assert st["step"] == 1234 and mr.get_step() == (1234, 0, 0)
+    live, ema = mr.read(losses.PARAM), mr.read(losses.EMA)
+    sd_live, sd_ema = synth.synth_state_dict(cfg_r, 0), synth.synth_state_dict(cfg_r, 7)
+    assert all(torch.equal(live[n], sd_live[n]) and torch.equal(ema[n], sd_ema[n]) for n in live)

@@ -1,5 +1,7 @@
 """Checkpoint side of the sampling driver: reference ``score_sde_pytorch/utils.py:11-26`` and
-``score_sde_pytorch/models/ema.py:51-93``, load side only.
+``score_sde_pytorch/models/ema.py:51-93``: the load side of the sampling driver, and (round 4) ``save_checkpoint`` /
+``restore_training_state`` for the training state of ``text2protein_amd.losses`` in the SAME file layout, so that a run trained
+here can be sampled -- or continued -- by the reference and the other way round.
 
 A reference checkpoint is ``torch.save({'optimizer', 'model', 'ema', 'step'})`` where ``model`` is a
 DataParallel state dict (every key prefixed ``module.``, plus the float64 buffer
@@ -58,3 +60,26 @@ def save_synthetic_checkpoint(path, config, seed=0):
              "step": 0}
     torch.save(state, path)
     return path
+
+
+def save_checkpoint(ckpt_dir, state):
+    """score_sde_pytorch/utils.py:19-26 for a training ``state`` of text2protein_amd.losses (``optimizer`` = AdamView, ``model`` =
+    HipTrainModel, ``ema`` = ExponentialMovingAverage view, ``step``): the reference's file layout, DataParallel key prefix and the
+    float64 ``sigmas`` buffer included, tensors on the CPU."""
+    from .model import get_sigmas
+    model = state["model"]
+    model_sd = {"module.sigmas": torch.tensor(get_sigmas(model.config))}
+    model_sd.update({"module." + k: v for k, v in model.state_dict().items()})
+    torch.save({"optimizer": state["optimizer"].state_dict(), "model": model_sd, "ema": state["ema"].state_dict(),
+                "step": int(state["step"])}, ckpt_dir)
+
+
+def restore_training_state(ckpt_dir, state, device="cpu"):
+    """score_sde_pytorch/utils.py:11-17: optimizer, model, EMA and step of a reference-layout checkpoint into ``state``."""
+    loaded = torch.load(ckpt_dir, map_location=device, weights_only=True)
+    state["model"].load_state_dict(strip_module_prefix(loaded["model"]), strict=False)
+    state["ema"].load_state_dict(loaded["ema"])
+    state["optimizer"].load_state_dict(loaded["optimizer"])
+    state["step"] = int(loaded["step"])
+    state["model"].set_step(state["step"])
+    return state

@@ -227,14 +227,36 @@ class AdamView:
         pass            # the native step zeroes the gradient buffer itself
 
     def state_dict(self):
-        step = self.model.get_step()[1]
-        return dict(step=step, exp_avg=self.model.read(EXP_AVG), exp_avg_sq=self.model.read(EXP_AVG_SQ), param_groups=self.param_groups)
+        """``torch.optim.Adam.state_dict()`` layout (what the reference's save_checkpoint stores, score_sde_pytorch/utils.py:19-26):
+        ``state`` = {parameter index: {step, exp_avg, exp_avg_sq}} in ``parameters()`` order (empty before the first update),
+        ``param_groups`` = one group listing every index."""
+        k = self.model.get_step()[1]
+        names = [s.name for s in self.model._specs]
+        state = {}
+        if k > 0:
+            m, v = self.model.read(EXP_AVG), self.model.read(EXP_AVG_SQ)
+            state = {i: {"step": torch.tensor(float(k)), "exp_avg": m[n], "exp_avg_sq": v[n]} for i, n in enumerate(names)}
+        g = dict(self.param_groups[0])
+        group = dict(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"], amsgrad=False, maximize=False,
+                     foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False,
+                     params=list(range(len(names))))
+        return dict(state=state, param_groups=[group])
 
     def load_state_dict(self, sd):
-        self.model.write(EXP_AVG, sd["exp_avg"])
-        self.model.write(EXP_AVG_SQ, sd["exp_avg_sq"])
+        names = [s.name for s in self.model._specs]
+        st = sd.get("state", {})
         cur = self.model.get_step()
-        self.model.set_step(cur[0], adam_updates=int(sd["step"]))
+        if not st:
+            self.model.set_step(cur[0], adam_updates=0)
+            return
+        if len(st) != len(names):
+            raise T2PError(f"optimizer state holds {len(st)} tensors, the model has {len(names)}")
+        self.model.write(EXP_AVG, {n: st[i]["exp_avg"] for i, n in enumerate(names)})
+        self.model.write(EXP_AVG_SQ, {n: st[i]["exp_avg_sq"] for i, n in enumerate(names)})
+        steps = {int(torch.as_tensor(st[i]["step"]).item()) for i in range(len(names))}
+        if len(steps) != 1:
+            raise T2PError("per-parameter Adam step counts differ: not a state this trainer can continue from")
+        self.model.set_step(cur[0], adam_updates=steps.pop())
 
 
 def get_optimizer(config, params):
