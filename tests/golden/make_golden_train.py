@@ -122,10 +122,22 @@ FULL_TENSORS = [   # one parameter of each kind whose gradient / post-step value
 def fixture(name):
     case = TRAIN_CASES[name]
     cfg = case["config"]()
+    if case.get("full_size"):        # the reference's OWN YAML for the reference model (the repo's configs/ hold views of it with the same values)
+        import yaml
+        from text2protein_amd.config import finalize_config
+        with open(os.path.join("/root/reference", "configs", "cond_length.yml")) as f:
+            cfg_ref = finalize_config(yaml.safe_load(f), **{"data.max_res_num": cfg.data.max_res_num, "model.num_scales": cfg.model.num_scales})
+        cfg_ref.device = "cpu"
+        for k in ("nf", "ch_mult", "num_res_blocks", "attn_resolutions", "dropout", "ema_rate", "condition", "n_heads", "context_dim"):
+            assert cfg_ref.model[k] == cfg.model[k], k
+        assert dict(cfg_ref.optim) == dict(cfg.optim)
+        cfg = cfg_ref
     inp = train_inputs(cfg, case)
     r = reference_step(cfg, case, inp)
     names = r["names"]
     full = [n for n in FULL_TENSORS + case.get("extra_full", []) if n in r["grads"]]
+    if case.get("full_size"):
+        full = [n for n in full if r["grads"][n].numel() <= 20000]
     # the oracle's restatement through its own functional forward
     loss_o, raw_o, P_o, st_o = oracle_step(cfg, case, inp, r["sd"])
     e_loss = abs(float(loss_o) - float(r["loss"])) / abs(float(r["loss"]))
@@ -136,7 +148,7 @@ def fixture(name):
     print(f"[{name}] loss {float(r['loss']):.6g} ({r['n_drop']} dropout calls); oracle vs reference: loss {e_loss:.2e}, worst gradient {e_g:.2e}, "
           f"worst post-step parameter {e_p:.2e}, worst EMA {e_e:.2e}; largest parameter move {moved:.3e}", flush=True)
     assert e_loss < 1e-6 and e_g < 1e-4 and e_p < 1e-6 and e_e < 1e-6 and moved > 0
-    out = {"loss": np.float64(r["loss"]), "score": r["score"].float().numpy(), "names": np.array(names), "n_dropout_calls": np.int64(r["n_drop"])}
+    out = {"loss": np.float64(r["loss"]), "score": (r["score"][:, :, ::8, ::8] if case.get("full_size") else r["score"]).float().numpy(), "names": np.array(names), "n_dropout_calls": np.int64(r["n_drop"])}
     for key in ("grads", "post", "ema", "m", "v"):
         out[key + "_norm"] = np.array([float(r[key][n].double().norm()) for n in names])
         out[key + "_proj"] = np.array([projection(n, r[key][n]) for n in names])

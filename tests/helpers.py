@@ -106,9 +106,18 @@ def cfg_train_tinyB():
                           "model.condition": ["length", "ss", "inpainting"], "model.dropout": 0.1, "model.num_scales": 50})
 
 
+def cfg_train_cond_length():
+    """BASELINE configs[2]'s model at its real size: configs/cond_length.yml, L = 128 (75.0 M parameters), dropout as shipped (0.1)."""
+    from text2protein_amd.config import load_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return load_config(os.path.join(root, "configs", "cond_length.yml"), **{"data.max_res_num": 128, "model.num_scales": 1000})
+
+
 TRAIN_CASES = {   # name -> what the fixture script and the tests share; step0 = state['step'] before the update (warm-up factor step0 / 5000)
     "train_tiny": dict(config=cfg_train_tiny, seed=3, B=2, T=3, lengths=[12, 9], step0=2000, mask_info=None),
     "train_tinyB": dict(config=cfg_train_tinyB, seed=4, B=3, T=5, lengths=[16, 11, 6], step0=7000, mask_info="1:3,6:8"),
+    # full size (round 4): norms + projections of all 622 tensors, whole tensors for the small ones only (the file stays ~1 MB)
+    "train_cond_length": dict(config=cfg_train_cond_length, seed=5, B=1, T=16, lengths=[100], step0=9000, mask_info=None, full_size=True),
 }
 
 
@@ -164,9 +173,14 @@ class CounterDropout:
         return self.module(input)
 
 
-def projection(name, tensor, seed=99):
-    """<tensor, r> with r ~ U(-1, 1) keyed by the tensor's name: pins every element of a tensor with one stored number."""
+def projection(name, tensor, seed=99, cache=None):
+    """<tensor, r> with r ~ U(-1, 1) keyed by the tensor's name: pins every element of a tensor with one stored number.
+    ``cache`` (a dict) keeps r between calls: the full-size fixture projects five buffers of 75 M elements on the same vectors."""
     from text2protein_amd import synth
     v = torch.as_tensor(tensor).detach().double().reshape(-1)
-    r = torch.from_numpy(synth.uniform_pm1(seed, name + ":proj", v.numel())).double()
-    return float((v * r).sum())
+    r = cache.get(name) if cache is not None else None
+    if r is None:
+        r = torch.from_numpy(synth.uniform_pm1(seed, name + ":proj", v.numel()))
+        if cache is not None:
+            cache[name] = r
+    return float((v * r.double()).sum())

@@ -193,12 +193,14 @@ def _dropout_masks(case, cfg, model):
     return masks
 
 
-@pytest.mark.parametrize("name", ["train_tiny", "train_tinyB"])
+@pytest.mark.parametrize("name", ["train_tiny", "train_tinyB", "train_cond_length"])
 def test_training_step_vs_reference(name):
     """ONE training step (losses.py:165-176) against autograd through the reference UNetModel: the loss, every gradient (norm + random
     projection for all tensors, element by element for one tensor of each kind), the parameters, the EMA and both Adam moments after
     the update.  train_tinyB runs with Dropout_0 active (counter-based keep-masks injected), up / down blocks, C = 8 and all three
-    conditions; the warm-up factor is step0 / 5000 resp. 1."""
+    conditions; the warm-up factor is step0 / 5000 resp. 1.  train_cond_length (round 4) is BASELINE configs[2]'s model at its REAL size
+    (cond_length.yml, L = 128, 75.0 M parameters in 622 tensors, 42 dropout masks, one sample of 100 residues): every tensor through its
+    norm and projection, the small ones element by element, the score on an 8-strided grid."""
     from text2protein_amd import losses, sde_lib
     g = load_golden(name)
     case = TRAIN_CASES[name]
@@ -215,7 +217,7 @@ def test_training_step_vs_reference(name):
                  ema=losses.ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate), step=case["step0"])
     # the loss and the score it is computed from, no update yet
     loss0, score = model.loss(batch, t=inp["t"], z=inp["z"], backward=True, return_score=True)
-    e_score = rel_l2(score.cpu(), g["score"])
+    e_score = rel_l2(score.cpu()[:, :, ::8, ::8] if case.get("full_size") else score.cpu(), g["score"])
     e_loss = abs(loss0 - float(g["loss"])) / abs(float(g["loss"]))
     grads = model.read(losses.GRAD)
     worst = {}
@@ -223,11 +225,12 @@ def test_training_step_vs_reference(name):
     # on both sides: differences are held against max(|tensor|, 3e-5 of the whole gradient's norm)
     T = float(g["grad_total_norm"])
     floor = {"grads": 3e-5 * T, "m": 3e-6 * T, "v": 1e-12 * T * T, "post": 0.0, "ema": 0.0}
+    pcache = {}
     for key, got, tol in (("grads", grads, GRAD_TOL),):
         for i, n in enumerate(names):
             scale = max(float(g[key + "_norm"][i]), floor[key], 1e-30)
             assert abs(float(got[n].double().norm()) - float(g[key + "_norm"][i])) <= tol * scale, (key, n)
-            assert abs(projection(n, got[n]) - float(g[key + "_proj"][i])) <= 10 * tol * scale, (key, n)
+            assert abs(projection(n, got[n], cache=pcache) - float(g[key + "_proj"][i])) <= 10 * tol * scale, (key, n)
     full = [k[5:] for k in g if k.startswith("grad:")]
     worst["grad"] = max(rel_l2(grads[n], g["grad:" + n]) for n in full)
     print(f"{name}: loss {loss0:.6f} (reference {float(g['loss']):.6f}, rel {e_loss:.1e}), score rel-L2 {e_score:.1e}, "
@@ -239,18 +242,21 @@ def test_training_step_vs_reference(name):
     assert abs(loss1 - loss0) <= 1e-6 * abs(loss0) and state["step"] == case["step0"] + 1
     assert model.get_step() == (case["step0"] + 1, 1, 1)
     post = {"post": model.read(losses.PARAM), "ema": model.read(losses.EMA), "m": model.read(losses.EXP_AVG), "v": model.read(losses.EXP_AVG_SQ)}
-    for key, tol in (("post", PARAM_TOL), ("ema", PARAM_TOL), ("m", GRAD_TOL), ("v", 2 * GRAD_TOL)):
+    # Adam's first update is lr g / (|g| + eps): sign-like, so an element whose gradient is within rounding of zero moves by up to lr on either
+    # side; at the full learning rate (step0 >= warmup) that is 3e-5 of a small bias tensor's norm: the full-size case gets 1e-4 there
+    ptol = 1e-4 if case.get("full_size") else PARAM_TOL
+    for key, tol in (("post", ptol), ("ema", ptol), ("m", GRAD_TOL), ("v", 2 * GRAD_TOL)):
         for i, n in enumerate(names):
             scale = max(float(g[key + "_norm"][i]), floor[key], 1e-30)
             assert abs(float(post[key][n].double().norm()) - float(g[key + "_norm"][i])) <= tol * scale, (key, n)
-            assert abs(projection(n, post[key][n]) - float(g[key + "_proj"][i])) <= 10 * tol * scale, (key, n)
+            assert abs(projection(n, post[key][n], cache=pcache) - float(g[key + "_proj"][i])) <= 10 * tol * scale, (key, n)
     worst["post"] = max(rel_l2(post["post"][n], g["post:" + n]) for n in full)
     # the update itself, not only parameters that barely move: (p_after - p_before) against the reference's
     from text2protein_amd import synth
     sd = synth.synth_state_dict(cfg, case["seed"])
     worst["delta"] = max(rel_l2(post["post"][n] - sd[n], torch.from_numpy(g["post:" + n]) - sd[n]) for n in full)
     print(f"{name}: post-step parameters worst rel-L2 {worst['post']:.1e}, parameter UPDATE worst rel-L2 {worst['delta']:.1e}")
-    assert worst["post"] < PARAM_TOL and worst["delta"] < 5e-3      # Adam's first update is lr * sign-like: g / (|g| + eps) amplifies tiny gradient differences
+    assert worst["post"] < ptol and worst["delta"] < (2e-2 if case.get("full_size") else 5e-3)   # (sign-like first update, see above)
     from test_gpu_baseline import _record
     _record(f"train_step_{name}", {"loss_rel": e_loss, "score_rel_l2": e_score, "grad_rel_l2": worst["grad"], "post_rel_l2": worst["post"],
                                    "update_rel_l2": worst["delta"]})
