@@ -200,6 +200,12 @@ int t2p_train_set_dropout_masks(t2p_trainer* t, const uint8_t* const* device_mas
 /* loss_host: host float; score_out (optional): device fp32 (batch, C, L, L), the score the loss was computed from */
 int t2p_train_loss(t2p_trainer* t, const t2p_train_batch* batch, int backward, float* loss_host, float* score_out, void* stream);
 int t2p_train_step(t2p_trainer* t, const t2p_train_batch* batch, float* loss_host, void* stream);
+/* Data-parallel training (the reference wraps the model in DataParallel, score_sde_pytorch/utils.py:8: one gradient over the whole
+ * batch): every process runs t2p_train_loss(backward = 1) on its shard, the flat gradient buffer (device fp32 [n], parameters() order,
+ * owned by the trainer) is averaged over the processes -- ONE RCCL all-reduce -- and t2p_train_apply runs optimize_fn + step += 1 +
+ * ema.update on it.  t2p_train_step = t2p_train_loss(backward = 1) + t2p_train_apply. */
+int t2p_train_grad_buffer(t2p_trainer* t, float** device_ptr, int64_t* n);
+int t2p_train_apply(t2p_trainer* t, void* stream);
 int t2p_train_eval_loss(t2p_trainer* t, const t2p_train_batch* batch, float* loss_host, void* stream);
 int64_t t2p_train_device_bytes(const t2p_trainer* t);
 /* the strided fp32 GEMM of the backward pass: C[z][m][n] = alpha sum_k A(z,m,k) B(z,k,n) + beta C, element strides as given

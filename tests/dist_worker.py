@@ -5,6 +5,9 @@
                               the max over ranks, ONE all_gather of the per-rank samples; rank 0 prints a JSON line
   gpu_global_batch <outdir>   (GPU box) fused sampler with the norm all-reduce hook: this rank's single chain of a
                               two-chain global batch, noise injected; saves its final sample
+  gpu_train_dp <outdir>       (GPU box) data-parallel training: this rank's half of a 4-sample batch, two steps through
+                              losses.get_step_fn(..., dist=...) (gradient all-reduce between backward and the update); saves its
+                              parameters, EMA and the losses
 """
 import json
 import os
@@ -69,5 +72,35 @@ def gpu_global_batch(outdir):
     dist.destroy_process_group()
 
 
+def gpu_train_dp(outdir):
+    from helpers import TRAIN_CASES, train_inputs
+    from text2protein_amd import losses, sde_lib, synth
+    rank, world, local = D.env_rank_world()
+    dev = torch.device("cuda", int(os.environ.get("T2P_FORCE_DEVICE", local)))
+    torch.cuda.set_device(dev)
+    dist = D.init_process_group(dev)
+    case = dict(TRAIN_CASES["train_tiny"], B=4, lengths=[12, 9, 16, 7], step0=6000)
+    cfg = case["config"]()
+    cfg.device = str(dev)
+    inp = train_inputs(cfg, case)
+    per = case["B"] // world
+    sl = slice(rank * per, (rank + 1) * per)
+    model = losses.HipTrainModel(cfg, device=str(dev), seed=1)
+    model.load_state_dict(synth.synth_state_dict(cfg, case["seed"]))
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=cfg.model.num_scales)
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), dist=dist)
+    state = dict(model=model, optimizer=losses.get_optimizer(cfg, model.parameters()),
+                 ema=losses.ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate), step=case["step0"])
+    batch = {k: inp[k][sl] for k in ("coords_6d", "mask_pair", "context")}
+    out = []
+    for it in range(2):
+        out.append(step_fn(state, batch, condition=cfg.model.condition, t=inp["t"][sl] * (0.8 ** it), z=inp["z"][sl]))
+    torch.cuda.synchronize()
+    torch.save({"losses": out, "param": model.read(losses.PARAM), "ema": model.read(losses.EMA), "step": model.get_step()},
+               os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
-    {"cpu_control_flow": cpu_control_flow, "gpu_global_batch": gpu_global_batch}[sys.argv[1]](sys.argv[2])
+    {"cpu_control_flow": cpu_control_flow, "gpu_global_batch": gpu_global_batch, "gpu_train_dp": gpu_train_dp}[sys.argv[1]](sys.argv[2])

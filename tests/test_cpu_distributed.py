@@ -41,6 +41,10 @@ def _worker(rank, world, port, q):
     xb = x + step * grad + torch.sqrt(step * 2) * noise
     full_a = D.gather_samples(xa.float(), dist)
     full_b = D.gather_samples(xb.float(), dist)
+    gsum = torch.full((5,), float(rank + 1))
+    D.allreduce_mean_(gsum, dist)                                   # data-parallel training: mean of the flat gradient over the ranks
+    lmean = D.mean_over_ranks(10.0 * (rank + 1), dist, "cpu")
+    assert torch.equal(gsum, torch.full((5,), (1 + world) / 2.0)) and abs(lmean - 5.0 * (1 + world)) < 1e-12
     all_x = D.gather_samples(x, dist)
     all_grad = D.gather_samples(grad, dist)
     all_noise = D.gather_samples(noise, dist)

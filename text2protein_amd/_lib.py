@@ -129,6 +129,8 @@ SIGNATURES = {
     "t2p_train_loss": (_i, [_vp, C.POINTER(TrainBatch), _i, C.POINTER(_f), _vp, _vp]),
     "t2p_train_step": (_i, [_vp, C.POINTER(TrainBatch), C.POINTER(_f), _vp]),
     "t2p_train_eval_loss": (_i, [_vp, C.POINTER(TrainBatch), C.POINTER(_f), _vp]),
+    "t2p_train_apply": (_i, [_vp, _vp]),
+    "t2p_train_grad_buffer": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
     "t2p_train_device_bytes": (_i64, [_vp]),
     "t2p_op_tgemm": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i, _i, _i, _i, _i64, _i64, _i64, _f, _f, _vp, _i, _i, _i, _i, _i, _vp]),
     "t2p_op_groupnorm_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),

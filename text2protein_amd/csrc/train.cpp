@@ -725,6 +725,10 @@ int Trainer::loss(const t2p_train_batch& b, bool backward, bool use_ema, float* 
 
 int Trainer::step(const t2p_train_batch& b, float* loss_host, hipStream_t s) {
   T2P_TRY(loss(b, true, false, loss_host, nullptr, s));
+  return apply(s);
+}
+
+int Trainer::apply(hipStream_t s) {
   // optimize_fn (losses.py:41-49)
   AdamArgs a;
   a.p = P_; a.g = Gr_; a.m = M_; a.v = V_; a.n = total_;

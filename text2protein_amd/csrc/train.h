@@ -44,8 +44,12 @@ class Trainer {
   int set_dropout_masks(const uint8_t* const* masks, int n);
   // loss_fn (losses.py:105-134); with `backward` also d loss / d parameters into the gradient buffer (zeroed first: optimizer.zero_grad())
   int loss(const t2p_train_batch& b, bool backward, bool use_ema, float* loss_host, float* score_out, hipStream_t s);
-  // step_fn with train=True (losses.py:165-176)
+  // step_fn with train=True (losses.py:165-176) = loss(backward) + apply()
   int step(const t2p_train_batch& b, float* loss_host, hipStream_t s);
+  // optimize_fn (losses.py:41-49) on the gradient buffer as it stands, state['step'] += 1, ema.update (ema.py:32-49).  Data-parallel training
+  // calls loss(backward), averages grad_buffer() over the ranks (one RCCL all-reduce of the flat buffer), then this
+  int apply(hipStream_t s);
+  float* grad_buffer() const { return Gr_; }
   int64_t device_bytes() const { return (int64_t)pool_.held_bytes(); }
 
  private:

@@ -109,6 +109,22 @@ int t2p_train_step(t2p_trainer* t, const t2p_train_batch* batch, float* loss_hos
   API_END
 }
 
+int t2p_train_apply(t2p_trainer* t, void* stream) {
+  API_BEGIN
+  T2P_REQUIRE(t, "null trainer");
+  return t->impl.apply((hipStream_t)stream);
+  API_END
+}
+
+int t2p_train_grad_buffer(t2p_trainer* t, float** device_ptr, int64_t* n) {
+  API_BEGIN
+  T2P_REQUIRE(t && device_ptr && n, "grad_buffer arguments");
+  *device_ptr = t->impl.grad_buffer();
+  *n = (int64_t)t->impl.num_elements();
+  return T2P_OK;
+  API_END
+}
+
 int t2p_train_eval_loss(t2p_trainer* t, const t2p_train_batch* batch, float* loss_host, void* stream) {
   API_BEGIN
   T2P_REQUIRE(t && batch, "null argument");

@@ -132,6 +132,22 @@ def all_ranks(value: float, dist=None, device="cpu"):
     return [float(o.item()) for o in out]
 
 
+def allreduce_mean_(t: torch.Tensor, dist=None) -> torch.Tensor:
+    """In-place mean over the ranks (data-parallel training: the flat gradient buffer, one collective)."""
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t.div_(dist.get_world_size())
+    return t
+
+
+def mean_over_ranks(value: float, dist=None, device="cpu") -> float:
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item()) / dist.get_world_size()
+
+
 def chain_ids(chains_per_rank: int, rank: int):
     """Global ids of the chains a rank owns (rank-major, the order ``gather_samples`` returns)."""
     return list(range(rank * chains_per_rank, (rank + 1) * chains_per_rank))

@@ -185,6 +185,24 @@ class HipTrainModel:
         check(self.lib.t2p_train_step(self._h, C.byref(tb), C.byref(out), stream_ptr()))
         return float(out.value)
 
+    def apply(self):
+        """optimize_fn + ``step += 1`` + ``ema.update`` (losses.py:41-49, 174-176; ema.py:32-49) on the gradient buffer as it stands."""
+        check(self.lib.t2p_train_apply(self._h, stream_ptr()))
+
+    def grad_view(self):
+        """The flat fp32 gradient buffer (every tensor in ``parameters()`` order) as a torch tensor sharing the trainer's device memory:
+        what data-parallel training all-reduces between ``loss(..., backward=True)`` and ``apply()``."""
+        p, n = C.c_void_p(), C.c_int64()
+        check(self.lib.t2p_train_grad_buffer(self._h, C.byref(p), C.byref(n)))
+
+        class _Buf:          # CUDA array interface: torch wraps the memory without copying
+            __cuda_array_interface__ = {"shape": (int(n.value),), "typestr": "<f4", "data": (int(p.value), False), "version": 2}
+
+        keep = _Buf()
+        t = torch.as_tensor(keep, device=self.device)
+        t._t2p_owner = (self, keep)
+        return t
+
     def eval_loss(self, batch, t=None, z=None):
         """``step_fn`` with train=False (losses.py:177-183): the loss under the EMA weights."""
         tb, hold = self._batch(batch, t, z)
@@ -333,10 +351,15 @@ def get_sde_loss_fn(sde, train, eps=1e-5):
     return loss_fn
 
 
-def get_step_fn(sde, train, optimize_fn=None):
-    """losses.py:140-186."""
+def get_step_fn(sde, train, optimize_fn=None, dist=None):
+    """losses.py:140-186.  ``dist`` (an initialised ``torch.distributed`` module, text2protein_amd.distributed.init_process_group):
+    data-parallel training, one process per GPU -- each rank takes its shard of the batch, the flat gradient buffer is averaged over
+    the ranks with ONE all-reduce (RCCL over xGMI) and every rank applies the same update; the returned loss is the mean over the
+    ranks.  With equal shards this is the reference's DataParallel step on the concatenated batch (the loss is a mean of per-sample
+    terms, losses.py:128-131)."""
     if not isinstance(sde, VESDE):
         raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
 
     def step_fn(state, batch, condition=None, t=None, z=None):
         model = state["model"]
@@ -351,7 +374,14 @@ def get_step_fn(sde, train, optimize_fn=None):
             if optimize_fn is not None:
                 optimize_fn(state["optimizer"], model.parameters(), step=state["step"])
             model.set_step(state["step"])
-            loss = model.step(batch, t=t, z=z)                    # zero_grad, loss, backward, optimize_fn, ema.update
+            if world == 1:
+                loss = model.step(batch, t=t, z=z)                # zero_grad, loss, backward, optimize_fn, ema.update
+            else:
+                from . import distributed as D
+                loss = model.loss(batch, t=t, z=z, backward=True)
+                D.allreduce_mean_(model.grad_view(), dist)        # one collective over the whole gradient
+                loss = D.mean_over_ranks(loss, dist, model.device)
+                model.apply()
             state["step"] += 1
             return loss
         return model.eval_loss(batch, t=t, z=z)                  # ema.store / copy_to / loss / restore (losses.py:177-183)
