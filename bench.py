@@ -29,6 +29,8 @@ The JSON line (rank 0), beyond the contract's keys:
   f32                       N = 1: the SAME workload on the exact-f32 engine (v_mfma_f32_32x32x2_f32, the reference's own
                             arithmetic type): --f32-steps (10) steps after a warm-up step, with its own kernel roofline
                             against the 157.3 TFLOP/s f32 matrix peak
+  train_step                N = 1: the fp32 training step (loss + backward + Adam + EMA) on cond_length.yml at full size, 16 samples: an
+                            extra, not the headline
   cpu_baseline              N = 1: the oracle on the host cores, 2 chains x 3 PC steps after one warm-up step, scaled by N
   cfg3, cfg5                N > 1: BASELINE configs[2] (cond_length.yml, 32 chains per GPU, length condition: the workload the north
                             star's 1000 samples/min is about) and configs[4] (cond_length_inpainting.yml, 16 chains per GPU, length +
@@ -79,6 +81,7 @@ def parse():
     ap.add_argument("--layers", default="", help="write the per-block times of one PC step (HIP events at block boundaries, CSV) to this file")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 engine's line (rank 0, N = 1)")
     ap.add_argument("--f32-steps", type=int, default=10)
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step line (rank 0, N = 1)")
     ap.add_argument("--no-cfg3", action="store_true", help="with --gpus N > 1: skip the additional cfg3 / cfg5 (BASELINE configs[2] / configs[4]) measurements")
     return ap.parse_args()
 
@@ -266,6 +269,42 @@ def kernel_roofline(job, stepper, lib, peak, shapes="", layers=""):
     }
 
 
+def train_step_line(dev, fname="cond_length.yml", batch=16, steps=3):
+    """The training step (reference losses.py:165-176: loss, backward, warm-up + clip + Adam, EMA), fp32, on BASELINE
+    configs[2]'s model at its real size: `batch` samples of 100 residues at L = 128, 512 text tokens, dropout as shipped, t / z / masks
+    drawn on the device; one warm-up step, then `steps` timed.  An extra of the line, not the headline: the reference publishes no
+    training figure.  FLOPs: 3 x the forward pass as executed (151.2 GFLOP per sample, text K / V projections included)."""
+    from text2protein_amd import losses, sde_lib, synth
+    from text2protein_amd.config import load_config
+    cfg = load_config(os.path.join(ROOT, "configs", fname), **{"data.max_res_num": 128, "model.num_scales": 1000})
+    cfg.device = str(dev)
+    model = losses.HipTrainModel(cfg, device=str(dev), seed=1)
+    model.load_state_dict(synth.synth_state_dict(cfg, 0))
+    B, C_, L = batch, cfg.data.num_channels, cfg.data.max_res_num
+    x = torch.from_numpy(synth.uniform_pm1(1, "bench_train_x", B * C_ * L * L).reshape(B, C_, L, L))
+    mp = torch.zeros(B, L, L).bool()
+    mp[:, :100, :100] = True
+    x = x * mp.unsqueeze(1)
+    x[:, -1] = mp.float()
+    b = dict(coords_6d=x.to(dev), mask_pair=mp.to(dev), context=synth.synth_context(B, 512, cfg.model.context_dim, 3).to(dev))
+    sde = sde_lib.VESDE(sigma_min=cfg.model.sigma_min, sigma_max=cfg.model.sigma_max, N=cfg.model.num_scales)
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg))
+    state = dict(model=model, optimizer=losses.get_optimizer(cfg, model.parameters()),
+                 ema=losses.ExponentialMovingAverage(model.parameters(), decay=cfg.model.ema_rate), step=5000)
+    seq = [step_fn(state, b, condition=cfg.model.condition)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        seq.append(step_fn(state, b, condition=cfg.model.condition))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tf = 151.2e9 * 3 * B / dt / 1e12
+    return {"value": B / dt, "unit": "training samples/s", "ms_per_step": dt * 1e3, "steps": steps, "warmup": 1, "dtype": "f32",
+            "workload": f"{fname} L=128 batch={B} text_tokens=512 dropout={cfg.model.dropout}: loss + backward + Adam + EMA",
+            "losses": [round(v, 5) for v in seq], "finite": all(v == v and abs(v) < 1e9 for v in seq),
+            "tflops_f32": tf, "frac_of_f32_mfma_peak": tf / MFMA_PEAK_TFLOPS["f32"], "device_gib": model.device_bytes() / 2 ** 30}
+
+
 def main():
     args = parse()
     from text2protein_amd import distributed as D            # imports torch; does not touch the GPU
@@ -362,6 +401,8 @@ def main():
         if not args.no_roofline:
             out["f32"]["roofline"] = kernel_roofline(job, st32, lib, MFMA_PEAK_TFLOPS["f32"])
         del st32, m32
+    if rank == 0 and world == 1 and not args.no_train and not args.no_f32:      # (the measurement tools pass --no-f32: no extras)
+        out["train_step"] = train_step_line(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(job.cfg, job.sd, job.ctx_cpu, N)
     if dist is not None:
