@@ -953,3 +953,38 @@ def test_small_map_convolution_with_its_groupnorm(lib, dt, B, HWs, C, Cout, CX0,
     # shapes it does not cover are refused
     assert lib.t2p_op_small_conv_groupnorm(dt, P(out), P(wk), wk.shape[1], None, 0, None, 0, None, None, None, 1.0, P(out), 0, None, None, 0, None,
                                            None, 1e-6, 0, 1, 16, 16, C, Cout, None) != 0
+
+
+@pytest.mark.parametrize("dt", [1, 2])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,CX", [(4, 128, 128, 128, 256, 0), (8, 128, 128, 64, 128, 0), (32, 64, 64, 128, 128, 0),
+                                               (16, 64, 64, 192, 256, 128), (2, 256, 256, 64, 128, 64), (4, 128, 128, 128, 128, 192)])
+def test_dx_shared_stage_convolution_is_bit_identical(lib, dt, B, H, W, Cin, Cout, CX):
+    """gemm_dxs_kernel (plan switch 47): the three horizontal taps of a window row read ONE LDS stage with shifted fragment rows, image-row
+    edges zeroed in the fragments.  Same K order, same MFMA order, same epilogue as the implicit-GEMM kernel: bit-identical outputs, with and
+    without the shortcut segment, on both tile geometries (N = 256: 256 x 256; N = 128: 512 x 128), W = 64 / 128 / 256 -- and both against
+    torch in fp64 (every image-row edge of every tile is exercised: the inputs have no zero border)."""
+    td = TDT[dt]
+    g = torch.Generator().manual_seed(B * 1000 + H + Cin + CX)
+    x = torch.randn(B, H, W, Cin, generator=g).to(td)
+    w = (torch.randn(Cout, 9 * Cin + CX, generator=g) / (9 * Cin + CX) ** 0.5).to(td)
+    bias = torch.randn(Cout, generator=g)
+    xs = torch.randn(B, H, W, CX, generator=g).to(td) if CX else None
+    dx_, dw, db = dev(x), dev(w), dev(bias)
+    dxs = dev(xs) if CX else None
+    outs = []
+    try:
+        for sw in (1, 0):
+            check(lib, lib.t2p_debug_set(47, sw))
+            out = torch.full((B, H, W, Cout), float("nan"), device="cuda", dtype=td)
+            check(lib, lib.t2p_op_conv3x3_shortcut(dt, P(dx_), P(dw), P(db), P(dxs) if CX else None, CX, None, 0, C.c_float(0.5), P(out), 0,
+                                                   B, H, W, Cin, Cout, None))
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+    finally:
+        lib.t2p_debug_set(47, 1)
+    assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
+    w9 = w[:, :9 * Cin].double().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w9, bias.double(), padding=1).permute(0, 2, 3, 1)
+    if CX:
+        ref = ref + xs.double() @ w[:, 9 * Cin:].double().T
+    assert rel_l2(outs[0].double(), 0.5 * ref) < TOL[dt]

@@ -598,6 +598,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 43) { t2p::g_st_tail_rows = value; return T2P_OK; }
   if (key == 45) { t2p::g_attn_fm = value != 0; return T2P_OK; }
   if (key == 46) { t2p::g_attn_proj = value != 0; return T2P_OK; }
+  if (key == 47) { set_gemm_dxs(value != 0); return T2P_OK; }
   if (key == 34) { set_gemm_a_norm(value != 0); return T2P_OK; }
   if (key == 32) { g_attn_merged = value != 0; return T2P_OK; }
   if (key == 33) { g_ffpo_merged = value != 0; return T2P_OK; }

@@ -153,7 +153,7 @@ struct DmaPlan { int geom, nsplit; };
 extern bool g_prof_on;
 extern std::vector<ProfRec> g_prof;
 extern int g_dma_ring, g_dbg;
-extern bool g_up4, g_deep_ring;
+extern bool g_up4, g_deep_ring, g_dxs;
 int num_cus();
 DmaPlan dma_plan(const GemmParams& p);
 int launch_splitk_reduce(const GemmParams& p, int nsplit, hipStream_t stream);
@@ -1478,6 +1478,258 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_cfrag_kernel(const Gemm
   gemm_dma_body<TC, BM, BN, WM, WN, MODE, NST, NSTB, true, true, true>(p, tiles_m, tiles_n, dbg_arg);
 }
 
+// =================================================================================================
+// v4 (round 4): 3x3 convolution at full resolution with the three HORIZONTAL taps of a window row served from one LDS stage.
+//
+// In the implicit GEMM above every input element lands in LDS nine times, once per tap: 96 KiB of activations per 64-channel chunk
+// and 256 x 256 tile, 4.8 GB of L2 -> LDS traffic per launch on cfg2's dominant layer; that stream costs the loop a quarter of its
+// matrix rate (1.57 -> 1.16 PFLOP/s, section 8 of DESIGN.md).  NHWC rows are pixel-major, so the rows a tile needs for tap
+// (dy, dx) are the rows of tap (dy, 0) shifted by dx: ONE stage [rows m + dy W of the tile] serves dx = -1, 0, +1 when the
+// fragment reads address row r + dx.  The two things that made the round-2 LDS-halo kernel lose are absent here:
+//   * no halo and no padding: a tile is whole image rows (BM % W == 0), so the rows r - 1 of the tile's first pixel and r + 1 of its
+//     last one are image-row edges, where the tap is zero anyway -- the stage is exactly the BM rows the kernel above stages;
+//   * the image-row edges inside a tile (x = 0 under dx = -1, x = W - 1 under dx = +1) cost four v_cndmask per affected 16-pixel
+//     tile and 32-deep step: with W a multiple of 64 only tiles 0 / 4 (left) and 3 / 7 (right) of a wave's 128 rows can be edges,
+//     a wave-uniform test each; no per-lane tap bookkeeping.
+// K order, weights layout, MFMA order and the register epilogue are those of gemm_dma_kernel<.., 1, 2, 2, true, true>: the results
+// are bit-identical.  Activation DMA drops to one third (one stage per (chunk, dy) instead of per tap) and has two K-tiles to land
+// instead of one; the weight stream is unchanged.  The 1x1 shortcut segment (X0 | X1) rides as single-tap groups at the end.
+template <typename TC, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_dxs_body(const GemmParams& p, const int tiles_m, const int tiles_n, const int dbg_arg) {
+  const int dbg = dbg_arg & (128 | 256);
+  constexpr int BK = 64, NW = WM * WN;
+  static_assert(NW == 8 && BM / WM == 128 && BN / WN == 64, "128 x 64 wave tiles, 8 wavefronts");
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;
+  // LDS: the weight ring FIRST, then the activation ring: row -1 of an activation stage (read by lane r = 0 of a wave's first tile under
+  // dx = -1, always an image-row edge, always zeroed) is then ordinary LDS memory, not an address below the allocation
+  constexpr int ASTAGE = BM * 128, BSTAGE = BN * 128, ARING = 2 * BSTAGE;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int ntiles = tiles_m * tiles_n;
+  int tile = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = tile & 7, idx = tile >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int Ctot = p.C0 + p.C1, nch = Ctot / BK, nchx = (p.CX0 + p.CX1) / BK;
+  const int ngroups = nch * 3 + nchx;                 // A stages: (chunk, dy) x 3 K-tiles each, then the shortcut chunks x 1 K-tile
+  const int HW = p.H * p.W, W = p.W;
+
+  const TC* A0p = (const TC*)p.A0;
+  const TC* Bp = (const TC*)p.Bw;
+  const long a_rows = p.M;
+  const int a0_bytes = (int)(((a_rows - 1) * p.lda0 + p.C0) * 2);
+  const int a1_bytes = p.A1 ? (int)(((a_rows - 1) * p.lda1 + p.C1) * 2) : 0;
+  const __amdgpu_buffer_rsrc_t rB = make_rsrc(Bp, (int)((((long)p.N - 1) * p.ldb + 9L * Ctot + nchx * BK) * 2));
+  const unsigned lda0_2 = (unsigned)(p.lda0 * 2), lda1_2 = (unsigned)(p.lda1 * 2);
+  const unsigned ldx0_2 = (unsigned)(p.ldx0 * 2), ldx1_2 = (unsigned)(p.ldx1 * 2);
+  const void* const X0p = p.X0; const void* const X1p = p.X1; const void* const A1p = p.A1;
+  const int pC0 = p.C0, pCX0 = p.CX0;
+  const int x0_bytes = nchx ? (int)((((long)p.M - 1) * p.ldx0 + p.CX0) * 2) : 0;
+  const int x1_bytes = (nchx && p.X1) ? (int)((((long)p.M - 1) * p.ldx1 + p.CX1) * 2) : 0;
+
+  // per-lane DMA geometry: the row of instruction j is a_m0 + 8 j; a_vmp packs the validity of the three window rows of all
+  // instructions (bit 3 j + dy + 1: m < M and 0 <= y + dy < H) -- two registers, whatever A_INSTR is
+  const int prow = lane >> 3, ppos = lane & 7;
+  unsigned a_chk[2];
+  a_chk[0] = (unsigned)((ppos ^ ((prow >> 1) & 7)) * 16);
+  a_chk[1] = (unsigned)((ppos ^ ((4 + (prow >> 1)) & 7)) * 16);
+  const unsigned a_m0 = (unsigned)(m0 + wave * A_INSTR * 8 + prow);
+  unsigned a_vmp = 0;
+  static_assert(A_INSTR * 3 <= 32, "validity bits of a wave's A instructions fit one register");
+#pragma unroll
+  for (int j = 0; j < A_INSTR; ++j) {
+    const int m = (int)a_m0 + 8 * j;
+    const int b = m / HW, y = (m - b * HW) / W;
+    if (m < p.M) a_vmp |= ((y > 0 ? 1u : 0u) | 2u | (y < p.H - 1 ? 4u : 0u)) << (3 * j);
+  }
+  unsigned b_off[B_INSTR];
+#pragma unroll
+  for (int j = 0; j < B_INSTR; ++j) {
+    const int r = (wave * B_INSTR + j) * 8 + prow;
+    const int n = n0 + (r & ~63) + hperm(r & 63);
+    b_off[j] = n < p.N ? (unsigned)((long)n * p.ldb * 2) + (unsigned)((ppos ^ ((r >> 1) & 7)) * 16) : DMA_OOB;
+  }
+
+  // ---- A stream: one stage per group --------------------------------------------------------------------------------------
+  int ga = 0;                                           // next group to issue
+  unsigned ia_so = 0;
+  auto issue_a = [&]() __attribute__((always_inline)) {
+    const bool extra = ga >= nch * 3;
+    const int chunk = extra ? ga - nch * 3 : ga / 3;
+    const int dyi = extra ? 1 : ga - chunk * 3;         // window row 0 .. 2 (the shortcut segment reads the output pixel itself)
+    const int c0 = chunk * BK;
+    int cfirst = pC0;
+    if (extra) cfirst = pCX0;
+    const bool second = c0 >= cfirst;
+    const int csrc = second ? c0 - cfirst : c0;
+    unsigned ld2 = lda0_2;
+    const void* abase = (const void*)A0p;
+    int abytes = a0_bytes;
+    if (extra) {
+      if (second) { ld2 = ldx1_2; abase = X1p; abytes = x1_bytes; } else { ld2 = ldx0_2; abase = X0p; abytes = x0_bytes; }
+    } else if (second) {
+      ld2 = lda1_2; abase = A1p; abytes = a1_bytes;
+    }
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(abase, abytes);
+    const unsigned delta = (unsigned)((dyi - 1) * W * (int)ld2 + csrc * 2);
+    const unsigned base = __umul24(a_m0, ld2) + delta;
+    const unsigned vb0 = a_chk[0] + base, vb1 = a_chk[1] + base;
+    const unsigned step = 8u * ld2;                     // 8 rows further per instruction
+    unsigned char* sta = smem + ARING + ia_so;
+#pragma unroll
+    for (int j = 0; j < A_INSTR; ++j) {
+      const unsigned voff = ((j & 1) ? vb1 : vb0) + (unsigned)j * step;
+      const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)a_vmp, (unsigned)(3 * j + dyi), 1u);
+      unsigned char* dst = sta + (wave * A_INSTR + j) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, T2P_LDS_PTR(dst), 16, (voff & m) | (DMA_OOB & ~m), 0, 0, 0);
+    }
+    ia_so ^= (unsigned)ASTAGE;
+    ++ga;
+  };
+  // ---- B stream: one stage per K-tile, K order (chunk, tap), then the shortcut columns ---------------------------------------
+  int ib_chunk = 0, ib_tap = 0;
+  unsigned ib_so = 0, b_kb = 0;
+  const unsigned Ctot2 = (unsigned)(Ctot * 2);
+  auto issue_b = [&]() __attribute__((always_inline)) {
+    unsigned char* stb = smem + ib_so;
+#pragma unroll
+    for (int j = 0; j < B_INSTR; ++j) {
+      unsigned char* dst = stb + (wave * B_INSTR + j) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, T2P_LDS_PTR(dst), 16, b_off[j] + b_kb, 0, 0, 0);
+    }
+    ib_so ^= (unsigned)BSTAGE;
+    ++ib_tap; b_kb += Ctot2;
+    if (ib_tap == 9) {
+      asm volatile("");
+      ++ib_chunk;
+      if (ib_chunk >= nch) { b_kb = (unsigned)((9L * Ctot + (ib_chunk - nch) * BK) * 2); ib_tap = 8; }
+      else { ib_tap = 0; b_kb += (unsigned)(BK * 2) - 9u * Ctot2; }
+    }
+  };
+
+  f32x4_t acc16[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: lane (r = lane & 15, g = lane >> 4) reads 16 bytes of row (wave rows + r + dx) at logical chunk 4 ks + g;
+  // 16-row tile i is i * 2048 bytes further with the same swizzle term (immediate offset).  Rows -1 / BM of a stage are read only by
+  // lanes the edge masks zero (they lie in the neighbouring ring stage / past the allocation, where LDS reads return zero).
+  unsigned a16[3][2], b16[2];
+  {
+    const int r = lane & 15, g = lane >> 4;
+    const int rb = wn * (BN / WN) + r;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int ra = wm * (BM / WM) + r + d - 1;         // (-1 for the first lane of the first wave row under dx = -1)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a16[d][ks] = (unsigned)(ARING + ra * 128 + (((4 * ks + g) ^ ((ra >> 1) & 7)) << 4));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) b16[ks] = (unsigned)(rb * 128 + (((4 * ks + g) ^ ((rb >> 1) & 7)) << 4));
+  }
+  // image-row edges inside this wave's 128 rows (W % 64 == 0: only these four tiles can hold one)
+  const int rowb = m0 + wm * (BM / WM);
+  const bool eL0 = rowb % W == 0, eL4 = (rowb + 64) % W == 0, eR3 = eL4, eR7 = (rowb + 128) % W == 0;
+  const bool is_r0 = (lane & 15) == 0, is_r15 = (lane & 15) == 15;
+  const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+
+  const unsigned lds_base = (unsigned)(unsigned long long)T2P_LDS_PTR(smem);
+  const bool early = g_stagger_dbg(dbg) && wave >= NW / 2;
+  const bool late = g_stagger_dbg(dbg) && !(dbg & 256) && !early;
+  unsigned ra_so = 0, rb_so = 0;
+  const int nk = nch * 9 + nchx;
+  int kt = 0;                                           // K-tile being multiplied (B stream position kt + 1 is the next issue)
+
+  // one K-tile: DX = 0 / 1 / 2 is the horizontal tap dx = DX - 1; `first`: first K-tile of its group (the next group's stage is
+  // requested here, behind the weight tile, and has until the group's last K-tile to land: WAIT_A says whether it may still be in flight)
+#define T2P_RD4(F, ADDR, I0)                                                                        \
+  lds_read_b128_2k<I0>(F[0], ADDR); lds_read_b128_2k<I0 + 1>(F[1], ADDR);                            \
+  lds_read_b128_2k<I0 + 2>(F[2], ADDR); lds_read_b128_2k<I0 + 3>(F[3], ADDR);
+#define T2P_W8(N, X, Y)                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(Y[0]), "+v"(Y[1]), \
+               "+v"(Y[2]), "+v"(Y[3]) : "n"(N));
+#define T2P_M16(A, B, I0)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)       \
+      Mma16<TC>::run(B[j], A[i], acc16[I0 + i][j]);
+  auto ktile = [&](auto DXC, auto FIRSTC, auto AFLYC) __attribute__((always_inline)) {
+    constexpr int DX = decltype(DXC)::value;
+    constexpr bool FIRST = decltype(FIRSTC)::value;     // issues the next group's A stage
+    constexpr bool AFLY = decltype(AFLYC)::value;       // the A stage requested one K-tile ago may still be in flight at the top
+    if constexpr (AFLY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool more_b = kt + 1 < nk, more_a = FIRST && ga < ngroups;
+    const unsigned sa_off = lds_base + ra_so, sb_off = lds_base + rb_so;
+    rb_so ^= (unsigned)BSTAGE;
+    u32x4_t B0[4], B1[4], AL[4], AH[4];
+    const unsigned aa0 = sa_off + a16[DX][0], aa1 = sa_off + a16[DX][1], bb0 = sb_off + b16[0], bb1 = sb_off + b16[1];
+    if (early) {
+      if (more_b) issue_b();
+      if (more_a) issue_a();
+    }
+    T2P_RD4(B0, bb0, 0)
+    T2P_RD4(AL, aa0, 0)
+    T2P_RD4(AH, aa0, 4)
+    T2P_W8(4, B0, AL)
+    if constexpr (DX == 0) { if (eL0 && is_r0) AL[0] = zero4; }
+    if constexpr (DX == 2) { if (eR3 && is_r15) AL[3] = zero4; }
+    T2P_M16(AL, B0, 0)
+    if (!early && !late && more_b) issue_b();
+    T2P_RD4(AL, aa1, 0)
+    T2P_W8(4, B0, AH)
+    if constexpr (DX == 0) { if (eL4 && is_r0) AH[0] = zero4; }
+    if constexpr (DX == 2) { if (eR7 && is_r15) AH[3] = zero4; }
+    T2P_M16(AH, B0, 4)
+    if (!early && !late && more_a) issue_a();
+    if (late && more_b) issue_b();
+    T2P_RD4(B1, bb1, 0)
+    T2P_RD4(AH, aa1, 4)
+    T2P_W8(4, B1, AL)
+    if constexpr (DX == 0) { if (eL0 && is_r0) AL[0] = zero4; }
+    if constexpr (DX == 2) { if (eR3 && is_r15) AL[3] = zero4; }
+    T2P_M16(AL, B1, 0)
+    if (late && more_a) issue_a();
+    T2P_W8(0, B1, AH)
+    if constexpr (DX == 0) { if (eL4 && is_r0) AH[0] = zero4; }
+    if constexpr (DX == 2) { if (eR7 && is_r15) AH[3] = zero4; }
+    T2P_M16(AH, B1, 4)
+    ++kt;
+  };
+#undef T2P_RD4
+#undef T2P_W8
+#undef T2P_M16
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  using Tt = std::true_type; using Ff = std::false_type;
+
+  issue_b();                                            // weight tile of K-tile 0
+  issue_a();                                            // stage of group 0
+  for (int g = 0; g < nch * 3; ++g) {
+    ktile(I0{}, Tt{}, Ff{});                            // dx = -1: requests group g + 1
+    ktile(I1{}, Ff{}, Tt{});                            // dx =  0: only the weight tile has to be there
+    ktile(I2{}, Ff{}, Ff{});                            // dx = +1
+    ra_so ^= (unsigned)ASTAGE;
+  }
+  for (int e = 0; e < nchx; ++e) {                      // shortcut segment: one K-tile per stage, read at the output pixel
+    ktile(I1{}, Tt{}, Ff{});
+    ra_so ^= (unsigned)ASTAGE;
+  }
+  reg_epilogue<TC, BM, BN, WM, WN>(p, acc16, m0, n0, 0, 0, 1, 0, 0);
+}
+template <typename TC, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_dxs_kernel(const GemmParams p, const int tiles_m, const int tiles_n, const int dbg_arg) {
+  gemm_dxs_body<TC, BM, BN, WM, WN>(p, tiles_m, tiles_n, dbg_arg);
+}
+
 
 #endif  // T2P_PART_DMA
 
@@ -1603,6 +1855,8 @@ static int launch_t(const GemmParams& p, hipStream_t stream) {
 // (160 KiB; measured equal to 1)
 int g_dma_ring = 2;
 void set_gemm_ring(int v) { g_dma_ring = v; }
+bool g_dxs = true;            // plan switch 47: full-resolution 3x3 convolutions on the dx-shared-stage kernel (gemm_dxs_kernel) where eligible
+void set_gemm_dxs(bool on) { g_dxs = on; }
 static int g_dma_geom = 0;   // 0 auto, 1 force 256x128x3, 2 force 128x128x2, 3 force 256x256x2, 4 force 512x128x2
 static bool g_splitk = true;
 static int g_force_nsplit = 0;   // development: > 0 forces that split-K factor wherever a workspace is attached
@@ -2073,6 +2327,46 @@ static int launch_dma_geom(const GemmParams& p, hipStream_t stream) {
   return T2P_OK;
 }
 
+// the dx-shared-stage kernel applies: a 3x3 convolution at full resolution on the 16x16x32 geometries whose tiles are whole image rows
+static bool dxs_eligible(const GemmParams& p, const DmaPlan& plan) {
+  if (!g_dxs || p.taps != 9 || p.a_up || plan.nsplit != 1 || (plan.geom != 1 && plan.geom != 3) || g_dma_ring != 2) return false;
+  if (p.nz0 * p.nz1 != 1 || p.c_frag || p.geglu) return false;
+  const int BM = plan.geom == 1 ? 256 : 512, HW = p.H * p.W;
+  if (p.W % 64 != 0 || BM % p.W != 0 || HW % BM != 0 || p.M % HW != 0) return false;
+  if ((p.CX0 + p.CX1) % 64 != 0) return false;
+  return reg_epilogue_ok(p, 1, 0);            // the kernel carries the register epilogue only
+}
+
+template <typename TC, int BM, int BN, int WM, int WN>
+static int launch_dxs(const GemmParams& p, hipStream_t stream) {
+  constexpr int smem = 2 * BM * 128 + 2 * BN * 128;
+  auto kern = gemm_dxs_kernel<TC, BM, BN, WM, WN>;
+  T2P_TRY(ensure_dynamic_lds((const void*)kern, smem));
+  const int tiles_m = p.M / BM, tiles_n = (p.N + BN - 1) / BN;
+  ProfRec rec;
+  if (g_prof_on) {
+    T2P_HIP_CHECK(hipEventCreate(&rec.a));
+    T2P_HIP_CHECK(hipEventCreate(&rec.b));
+    prof_shape(rec, p);
+    rec.flops = 2.0 * p.M * p.N * (9.0 * (p.C0 + p.C1) + p.CX0 + p.CX1);
+    rec.kind = 0;
+    static const std::string kname = std::string("gemm_dxs_kernel<") + (dtype_of<TC>::value == DT_F16 ? "f16_t" : "bf16_t") + ", " +
+                                     std::to_string(BM) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ">";
+    rec.name = kname.c_str();
+    const double Ct = p.C0 + p.C1, Cx = p.CX0 + p.CX1;
+    rec.bytes = (double)p.M * Ct * 2 + (double)p.N * 9 * Ct * 2 + (double)p.M * Cx * 2 + (double)p.N * Cx * 2 + (double)p.M * p.N * (p.c_f32 ? 4 : 2) +
+                (p.R ? (double)p.M * p.N * (p.r_lowp ? 2 : 4) : 0.0) + (p.bias_bn ? (double)(p.M / p.rows_per_batch) * p.N * 4 : 0.0);
+    T2P_HIP_CHECK(hipEventRecord(rec.a, stream));
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WM * WN * 64), smem, stream, p, tiles_m, tiles_n, g_dbg);
+  if (g_prof_on) {
+    T2P_HIP_CHECK(hipEventRecord(rec.b, stream));
+    g_prof.push_back(rec);
+  }
+  T2P_HIP_CHECK(hipGetLastError());
+  return T2P_OK;
+}
+
 // a 3x3 convolution on a 2x up-sampled map as four 2x2 convolutions on the source map (kernel MODE 3): the caller supplied
 // the phase weights (GemmParams::Bw4), the 16x16x32 geometries with the register epilogue run it
 static bool up4_eligible(const GemmParams& p, const DmaPlan& plan) {
@@ -2102,6 +2396,12 @@ int launch_dma_mode(const GemmParams& p, hipStream_t stream) {
       q.up_phase = 5;                  // all four phases in one launch (grid.y = phase)
       if (plan.geom == 1) return launch_dma_geom<TC, 3, 256, 256, 2, 4, 2, 2, true, true>(q, stream);
       return launch_dma_geom<TC, 3, 512, 128, 4, 2, 2, 2, true, true>(q, stream);
+    }
+  }
+  if constexpr (MODE == 1) {
+    if (dxs_eligible(p, plan)) {
+      if (plan.geom == 1) return launch_dxs<TC, 256, 256, 2, 4>(p, stream);
+      return launch_dxs<TC, 512, 128, 4, 2>(p, stream);
     }
   }
   switch (plan.geom) {

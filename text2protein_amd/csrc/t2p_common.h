@@ -187,6 +187,7 @@ void set_gemm_a_norm(bool on);
 void set_gemm_up4(bool on);
 void set_gemm_deep_ring(bool on);
 void set_gemm_fuse_shortcut(bool on);
+void set_gemm_dxs(bool on);
 extern bool g_qkv_fused;
 extern bool g_attn_merged, g_ffpo_merged;
 extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible

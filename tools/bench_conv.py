@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--taps", type=int, default=9)
     ap.add_argument("--dbg", type=int, default=0)
     ap.add_argument("--geom", type=int, default=0)
-    ap.add_argument("--ring", type=int, default=0)
+    ap.add_argument("--ring", type=int, default=2, help="t2p_debug_set(8, .): 2 = the 16x16x32 kernels with the register epilogue (what the engine runs), 1 = 32x32x16")
     ap.add_argument("--no-dma", action="store_true")
     ap.add_argument("--c16", action="store_true", help="compute-dtype output instead of fp32")
     ap.add_argument("--nsplit", type=int, default=0, help="force this split-K factor (conv only; attaches a workspace)")
