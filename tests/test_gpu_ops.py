@@ -973,7 +973,7 @@ def test_dx_shared_stage_convolution_is_bit_identical(lib, dt, B, H, W, Cin, Cou
     dxs = dev(xs) if CX else None
     outs = []
     try:
-        for sw in (1, 0):
+        for sw in (1, 1, 1, 0):          # (three runs of the new kernel: a missing wait in its DMA ring shows up as run-to-run differences)
             check(lib, lib.t2p_debug_set(47, sw))
             out = torch.full((B, H, W, Cout), float("nan"), device="cuda", dtype=td)
             check(lib, lib.t2p_op_conv3x3_shortcut(dt, P(dx_), P(dw), P(db), P(dxs) if CX else None, CX, None, 0, C.c_float(0.5), P(out), 0,
@@ -982,7 +982,7 @@ def test_dx_shared_stage_convolution_is_bit_identical(lib, dt, B, H, W, Cin, Cou
             outs.append(out.cpu())
     finally:
         lib.t2p_debug_set(47, 1)
-    assert torch.isfinite(outs[0].float()).all() and torch.equal(outs[0], outs[1])
+    assert torch.isfinite(outs[0].float()).all() and all(torch.equal(outs[0], o) for o in outs[1:])
     w9 = w[:, :9 * Cin].double().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
     ref = F.conv2d(x.double().permute(0, 3, 1, 2), w9, bias.double(), padding=1).permute(0, 2, 3, 1)
     if CX:

@@ -1649,6 +1649,7 @@ __device__ __forceinline__ void gemm_dxs_body(const GemmParams& p, const int til
   unsigned ra_so = 0, rb_so = 0;
   const int nk = nch * 9 + nchx;
   int kt = 0;                                           // K-tile being multiplied (B stream position kt + 1 is the next issue)
+  bool a_requested = false;                             // the first K-tile of the running group requested the next group's stage
 
   // one K-tile: DX = 0 / 1 / 2 is the horizontal tap dx = DX - 1; `first`: first K-tile of its group (the next group's stage is
   // requested here, behind the weight tile, and has until the group's last K-tile to land: WAIT_A says whether it may still be in flight)
@@ -1665,10 +1666,13 @@ __device__ __forceinline__ void gemm_dxs_body(const GemmParams& p, const int til
     constexpr int DX = decltype(DXC)::value;
     constexpr bool FIRST = decltype(FIRSTC)::value;     // issues the next group's A stage
     constexpr bool AFLY = decltype(AFLYC)::value;       // the A stage requested one K-tile ago may still be in flight at the top
-    if constexpr (AFLY) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR) : "memory");
+    // (the weight tile of this K-tile was requested BEFORE the activation stage that may still be in flight: loads land in order, so
+    // "at most the stage's A_INSTR loads outstanding" means the weight tile is there -- but only if that stage was requested at all)
+    if (AFLY && a_requested) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_INSTR) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const bool more_b = kt + 1 < nk, more_a = FIRST && ga < ngroups;
+    if constexpr (FIRST) a_requested = more_a;
     const unsigned sa_off = lds_base + ra_so, sb_off = lds_base + rb_so;
     rb_so ^= (unsigned)BSTAGE;
     u32x4_t B0[4], B1[4], AL[4], AH[4];
