@@ -1538,9 +1538,12 @@ __device__ __forceinline__ void gemm_dxs_body(const GemmParams& p, const int til
   // per-lane DMA geometry: the row of instruction j is a_m0 + 8 j; a_vmp packs the validity of the three window rows of all
   // instructions (bit 3 j + dy + 1: m < M and 0 <= y + dy < H) -- two registers, whatever A_INSTR is
   const int prow = lane >> 3, ppos = lane & 7;
-  unsigned a_chk[2];
-  a_chk[0] = (unsigned)((ppos ^ ((prow >> 1) & 7)) * 16);
-  a_chk[1] = (unsigned)((ppos ^ ((4 + (prow >> 1)) & 7)) * 16);
+  // activation swizzle: 16-byte chunk c of stage row r sits at chunk c ^ (r & 6).  ds_read_b128 is served in the lane groups
+  // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32): rows {0-3, 12-15} at chunk c together with rows {4-11} at chunk c ^ 1.  The
+  // usual (r >> 1) & 7 term is conflict-free for that only while lane parity = row parity; under the +-1 row shift of the dx taps it
+  // is 2-way on a quarter of the slots (SQ_LDS_BANK_CONFLICT 19.9 M per launch at 256x256).  r & 6 is conflict-free at all three
+  // shifts (and has period 8: one source offset for every instruction).
+  const unsigned a_chk = (unsigned)((ppos ^ (prow & 6)) * 16);
   const unsigned a_m0 = (unsigned)(m0 + wave * A_INSTR * 8 + prow);
   unsigned a_vmp = 0;
   static_assert(A_INSTR * 3 <= 32, "validity bits of a wave's A instructions fit one register");
@@ -1581,12 +1584,12 @@ __device__ __forceinline__ void gemm_dxs_body(const GemmParams& p, const int til
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(abase, abytes);
     const unsigned delta = (unsigned)((dyi - 1) * W * (int)ld2 + csrc * 2);
     const unsigned base = __umul24(a_m0, ld2) + delta;
-    const unsigned vb0 = a_chk[0] + base, vb1 = a_chk[1] + base;
+    const unsigned vb0 = a_chk + base;
     const unsigned step = 8u * ld2;                     // 8 rows further per instruction
     unsigned char* sta = smem + ARING + ia_so;
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
-      const unsigned voff = ((j & 1) ? vb1 : vb0) + (unsigned)j * step;
+      const unsigned voff = vb0 + (unsigned)j * step;
       const unsigned m = (unsigned)__builtin_amdgcn_sbfe((int)a_vmp, (unsigned)(3 * j + dyi), 1u);
       unsigned char* dst = sta + (wave * A_INSTR + j) * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, T2P_LDS_PTR(dst), 16, (voff & m) | (DMA_OOB & ~m), 0, 0, 0);
@@ -1632,7 +1635,7 @@ __device__ __forceinline__ void gemm_dxs_body(const GemmParams& p, const int til
     for (int d = 0; d < 3; ++d) {
       const int ra = wm * (BM / WM) + r + d - 1;         // (-1 for the first lane of the first wave row under dx = -1)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) a16[d][ks] = (unsigned)(ARING + ra * 128 + (((4 * ks + g) ^ ((ra >> 1) & 7)) << 4));
+      for (int ks = 0; ks < 2; ++ks) a16[d][ks] = (unsigned)(ARING + ra * 128 + (((4 * ks + g) ^ (ra & 6)) << 4));
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) b16[ks] = (unsigned)(rb * 128 + (((4 * ks + g) ^ ((rb >> 1) & 7)) << 4));

@@ -1,7 +1,7 @@
 # Official per-round measurement pass (run on the GPU box through gpurun; outputs under gpurun_out/).
-#   bash tools/collect_profiles.sh r03
+#   bash tools/collect_profiles.sh r04
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32"
 echo "[1/10] default bench"; python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err

@@ -15,7 +15,7 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEEP = ("gemm_dma_kernel", "attn_flash_kernel", "attn_strip_kernel", "gemm_kernel", "gn_apply_kernel", "gn_apply16_kernel", "splitk_reduce_gn_kernel")
+KEEP = ("gemm_dxs_kernel", "gemm_dma_kernel", "attn_flash_kernel", "attn_strip_kernel", "gemm_kernel", "gn_apply_kernel", "gn_apply16_kernel", "splitk_reduce_gn_kernel")
 
 
 def short(name):
