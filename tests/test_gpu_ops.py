@@ -957,12 +957,14 @@ def test_small_map_convolution_with_its_groupnorm(lib, dt, B, HWs, C, Cout, CX0,
 
 @pytest.mark.parametrize("dt", [1, 2])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,CX", [(4, 128, 128, 128, 256, 0), (8, 128, 128, 64, 128, 0), (32, 64, 64, 128, 128, 0),
-                                               (16, 64, 64, 192, 256, 128), (2, 256, 256, 64, 128, 64), (4, 128, 128, 128, 128, 192)])
+                                               (16, 64, 64, 192, 256, 128), (2, 256, 256, 64, 128, 64), (4, 128, 128, 128, 128, 192),
+                                               (20, 128, 128, 64, 128, 0), (44, 64, 64, 64, 128, 64)])
 def test_dx_shared_stage_convolution_is_bit_identical(lib, dt, B, H, W, Cin, Cout, CX):
     """gemm_dxs_kernel (plan switch 47): the three horizontal taps of a window row read ONE LDS stage with shifted fragment rows, image-row
     edges zeroed in the fragments.  Same K order, same MFMA order, same epilogue as the implicit-GEMM kernel: bit-identical outputs, with and
     without the shortcut segment, on both tile geometries (N = 256: 256 x 256; N = 128: 512 x 128), W = 64 / 128 / 256 -- and both against
-    torch in fp64 (every image-row edge of every tile is exercised: the inputs have no zero border)."""
+    torch in fp64 (every image-row edge of every tile is exercised: the inputs have no zero border).  The last two
+    shapes are several rounds of tiles (640 and 352 tiles of 512 rows), their fp64 reference taken on a few samples."""
     td = TDT[dt]
     g = torch.Generator().manual_seed(B * 1000 + H + Cin + CX)
     x = torch.randn(B, H, W, Cin, generator=g).to(td)
@@ -983,8 +985,9 @@ def test_dx_shared_stage_convolution_is_bit_identical(lib, dt, B, H, W, Cin, Cou
     finally:
         lib.t2p_debug_set(47, 1)
     assert torch.isfinite(outs[0].float()).all() and all(torch.equal(outs[0], o) for o in outs[1:])
+    sel = list(range(B)) if B <= 16 else [0, 1, B // 2, B - 2, B - 1]      # (the fp64 reference of the large shapes: a few samples)
     w9 = w[:, :9 * Cin].double().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
-    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w9, bias.double(), padding=1).permute(0, 2, 3, 1)
+    ref = F.conv2d(x[sel].double().permute(0, 3, 1, 2), w9, bias.double(), padding=1).permute(0, 2, 3, 1)
     if CX:
-        ref = ref + xs.double() @ w[:, 9 * Cin:].double().T
-    assert rel_l2(outs[0].double(), 0.5 * ref) < TOL[dt]
+        ref = ref + xs[sel].double() @ w[:, 9 * Cin:].double().T
+    assert rel_l2(outs[0][sel].double(), 0.5 * ref) < TOL[dt]

@@ -607,7 +607,7 @@ int t2p_debug_set(int key, int value) {
   if (key == 0) set_gemm_dma(value != 0);
   else if (key == 1) {
 #ifndef T2P_ABLATION
-    if (value & ~(128 | 256 | 4096)) {
+    if (value & ~(128 | 256 | 4096 | 8192)) {        // (8192: the general register epilogue where the specialised one would run -- same results)
       set_last_error("ablation bits that skip work exist only in a -DT2P_ABLATION build");
       return T2P_ERR_INVALID;
     }
@@ -625,6 +625,10 @@ int t2p_debug_set(int key, int value) {
   else return T2P_ERR_INVALID;
   return T2P_OK;
 }
+
+#ifdef T2P_ABLATION
+extern "C" int t2p_ablation_dxs_stamps(unsigned long long* out, int n) { return t2p::dxs_stamps_read(out, n); }
+#endif
 
 int t2p_built_with_ablation(void) {
 #ifdef T2P_ABLATION

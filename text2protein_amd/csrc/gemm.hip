@@ -785,7 +785,10 @@ __device__ __forceinline__ float row16_sum(float x) {
 #ifndef T2P_C_AUX
 #define T2P_C_AUX 0          // cache policy of the register epilogue's 16-bit output stores (measurement variants: 2 nt, 16 sc1, 17 sc0 sc1)
 #endif
-template <typename TC, int BM, int BN, int WM, int WN, bool CFRAG = false>
+// PLAIN: the caller knows at compile time that the launch is the network's common case -- 16-bit output, no split-K workspace, no GEGLU,
+// no per-row bias, no up-sampling phase: the per-tile uniform branches on those (a dozen per 16-row tile) and their scalar bookkeeping
+// fold away.  Same arithmetic, same order: bit-identical to the general form.
+template <typename TC, int BM, int BN, int WM, int WN, bool CFRAG = false, bool PLAIN = false>
 __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc16)[8][4], const int m0, const int n0, const int z0,
                                              const int z1, const int nsplit, const int ks, const int dbg) {
   if ((dbg & 1) && acc16[0][0][0] != 123.456f) return;
@@ -797,18 +800,21 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
   const long coff = (long)z0 * p.sC_z0 + (long)z1 * p.sC_z1;
   const float* R = p.R ? (p.r_lowp ? (const float*)((const uint16_t*)p.R + (long)z0 * p.sR_z0 + (long)z1 * p.sR_z1)
                                    : p.R + (long)z0 * p.sR_z0 + (long)z1 * p.sR_z1) : nullptr;
-  float* ws = nsplit > 1 ? (float*)p.ws + (long)ks * p.M * p.N : nullptr;
-  const int c_cols = p.geglu ? p.N / 2 : p.N;
-  const long c_bytes = ws ? (long)p.M * p.N * 4 : ((long)(p.M - 1) * p.ldc + c_cols) * (p.c_f32 ? 4 : 2);
+  static_assert(!(PLAIN && CFRAG), "the plain form stores row-major only");
+  float* ws = (!PLAIN && nsplit > 1) ? (float*)p.ws + (long)ks * p.M * p.N : nullptr;
+  const bool p_geglu = PLAIN ? false : p.geglu != 0, p_c_f32 = PLAIN ? false : p.c_f32 != 0;
+  const float* const p_bias_m = PLAIN ? nullptr : p.bias_m;
+  const int c_cols = p_geglu ? p.N / 2 : p.N;
+  const long c_bytes = ws ? (long)p.M * p.N * 4 : ((long)(p.M - 1) * p.ldc + c_cols) * (p_c_f32 ? 4 : 2);
   const long r_rows = p.r_up ? (long)(p.M / HW) * (p.H >> 1) * (p.W >> 1) : (long)p.M;
   const long r_bytes = R ? ((r_rows - 1) * p.ldr + p.N) * (p.r_lowp ? 2 : 4) : 0;
   const __amdgpu_buffer_rsrc_t rC =
-      make_rsrc(ws ? (const void*)ws : (p.c_f32 ? (const void*)((float*)p.C + coff) : (const void*)((TC*)p.C + coff)), (int)c_bytes);
+      make_rsrc(ws ? (const void*)ws : (p_c_f32 ? (const void*)((float*)p.C + coff) : (const void*)((TC*)p.C + coff)), (int)c_bytes);
   const __amdgpu_buffer_rsrc_t rR = make_rsrc(R ? (const void*)R : (const void*)p.C, (int)r_bytes);
 
   const int row_w = m0 + wm * (BM / WM);                 // first row of the wave tile (128 rows = 8 tiles of 16)
   // up_phase (MODE 3): rows are pixels of the half-resolution map; row (b, yl, xl) is stored at output pixel (b, 2 yl + py, 2 xl + px)
-  const int upp = p.up_phase == 5 ? 1 + (int)blockIdx.y : p.up_phase;     // 5: all four phases in one launch, the phase on grid.y
+  const int upp = PLAIN ? 0 : (p.up_phase == 5 ? 1 + (int)blockIdx.y : p.up_phase);     // 5: all four phases in one launch, the phase on grid.y
   const int Mrows = upp ? p.M >> 2 : p.M;
   const int Wl = p.W >> 1, HWl = (p.H >> 1) * (p.W >> 1);
   const int col0 = n0 + wn * (BN / WN) + 8 * g4;         // this lane's channels: [col0, col0 + 8) and [col0 + 32, col0 + 40)
@@ -839,7 +845,7 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
       }
     }
   }
-  const unsigned esz = (ws || p.c_f32) ? 4u : 2u;
+  const unsigned esz = (ws || p_c_f32) ? 4u : 2u;
   const unsigned ldc_e = ws ? (unsigned)p.N : (unsigned)p.ldc;
   const unsigned rsz = p.r_lowp ? 2u : 4u;
   const bool nostore = (dbg & 1024) != 0;
@@ -895,7 +901,7 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
       for (int e = 0; e < 4; ++e) v[4 * j + e] = acc16[i][j][e];       // v[k]: channel col0 + (k & 7) + 32 (k >> 3)
     if (!ws) {
       float bm = 0.f;
-      if (p.bias_m) bm = row < p.M ? p.bias_m[row] : 0.f;
+      if (p_bias_m) bm = row < p.M ? p_bias_m[row] : 0.f;
       if (p.bias_bn && bsel > 0) {                       // the tile runs into a following sample (small maps): per-tile reload
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -923,7 +929,7 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
       }
     }
     const bool rok = row < p.M && !nostore;
-    if (!ws && p.geglu) {
+    if (!ws && p_geglu) {
       // interleaved (value, gate) columns: out[row][c / 2] = value * gelu_erf(gate)  (GEGLU.forward, model/attention.py:42-44)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -1494,6 +1500,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_dma_cfrag_kernel(const Gemm
 // K order, weights layout, MFMA order and the register epilogue are those of gemm_dma_kernel<.., 1, 2, 2, true, true>: the results
 // are bit-identical.  Activation DMA drops to one third (one stage per (chunk, dy) instead of per tap) and has two K-tiles to land
 // instead of one; the weight stream is unchanged.  The 1x1 shortcut segment (X0 | X1) rides as single-tap groups at the end.
+#ifdef T2P_ABLATION
+// in-kernel timeline of the dx-shared kernel (measurement builds only): per tile, s_memtime of wave 0 at entry, before the K loop, after
+// the first K-tile's data landed, after the K loop, after the epilogue issued its stores and after they drained
+constexpr int DXS_STAMP_TILES = 4096, DXS_STAMPS = 8;
+static __device__ unsigned long long g_dxs_stamps[DXS_STAMP_TILES * DXS_STAMPS];      // one per translation unit; the f16 one is read
+#define T2P_STAMP(K) do { if (blockIdx.x < DXS_STAMP_TILES && threadIdx.x == 0) g_dxs_stamps[blockIdx.x * DXS_STAMPS + (K)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define T2P_STAMP_RT(K) do { if (blockIdx.x < DXS_STAMP_TILES && threadIdx.x == 0) g_dxs_stamps[blockIdx.x * DXS_STAMPS + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#if T2P_GEMM_PART == -1 || T2P_GEMM_PART == 2
+int dxs_stamps_read(unsigned long long* out, int n) {
+  if (n > DXS_STAMP_TILES * DXS_STAMPS) n = DXS_STAMP_TILES * DXS_STAMPS;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dxs_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? n : -1;
+}
+#endif
+#else
+#define T2P_STAMP(K) do { } while (0)
+#define T2P_STAMP_RT(K) do { } while (0)
+#endif
 template <typename TC, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void gemm_dxs_body(const GemmParams& p, const int tiles_m, const int tiles_n, const int dbg_arg) {
   const int dbg = dbg_arg & (128 | 256);
@@ -1505,6 +1528,8 @@ __device__ __forceinline__ void gemm_dxs_body(const GemmParams& p, const int til
   constexpr int ASTAGE = BM * 128, BSTAGE = BN * 128, ARING = 2 * BSTAGE;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+  T2P_STAMP(0);
+  T2P_STAMP_RT(6);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -1535,8 +1560,10 @@ __device__ __forceinline__ void gemm_dxs_body(const GemmParams& p, const int til
   const int x0_bytes = nchx ? (int)((((long)p.M - 1) * p.ldx0 + p.CX0) * 2) : 0;
   const int x1_bytes = (nchx && p.X1) ? (int)((((long)p.M - 1) * p.ldx1 + p.CX1) * 2) : 0;
 
-  // per-lane DMA geometry: the row of instruction j is a_m0 + 8 j; a_vmp packs the validity of the three window rows of all
-  // instructions (bit 3 j + dy + 1: m < M and 0 <= y + dy < H) -- two registers, whatever A_INSTR is
+  // DMA geometry.  The row of instruction j is a_m0 + 8 j (per lane).  The 8 rows of an instruction lie in one image row (W % 8 == 0) and
+  // the tile in one sample (HW % BM == 0), so the validity of its three window rows is WAVE-UNIFORM: a_vmp, a scalar, packs it for all
+  // instructions (bit 3 j + dy + 1: 0 <= y + dy < H; every row is < M since M % BM == 0) -- two integer divisions per tile, on the
+  // scalar unit, instead of two per instruction and lane
   const int prow = lane >> 3, ppos = lane & 7;
   // activation swizzle: 16-byte chunk c of stage row r sits at chunk c ^ (r & 6).  ds_read_b128 is served in the lane groups
   // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32): rows {0-3, 12-15} at chunk c together with rows {4-11} at chunk c ^ 1.  The
@@ -1545,13 +1572,18 @@ __device__ __forceinline__ void gemm_dxs_body(const GemmParams& p, const int til
   // shifts (and has period 8: one source offset for every instruction).
   const unsigned a_chk = (unsigned)((ppos ^ (prow & 6)) * 16);
   const unsigned a_m0 = (unsigned)(m0 + wave * A_INSTR * 8 + prow);
-  unsigned a_vmp = 0;
+  unsigned a_vmp;
   static_assert(A_INSTR * 3 <= 32, "validity bits of a wave's A instructions fit one register");
+  {
+    const int lgW = 31 - __builtin_clz(W);              // W is a power of two (dxs_eligible)
+    const int b = m0 / HW, y0 = (m0 - b * HW) >> lgW, Hm1 = p.H - 1;
+    unsigned v = 0;
 #pragma unroll
-  for (int j = 0; j < A_INSTR; ++j) {
-    const int m = (int)a_m0 + 8 * j;
-    const int b = m / HW, y = (m - b * HW) / W;
-    if (m < p.M) a_vmp |= ((y > 0 ? 1u : 0u) | 2u | (y < p.H - 1 ? 4u : 0u)) << (3 * j);
+    for (int j = 0; j < A_INSTR; ++j) {
+      const int y = y0 + (((wave * A_INSTR + j) * 8) >> lgW);
+      v |= ((y > 0 ? 1u : 0u) | 2u | (y < Hm1 ? 4u : 0u)) << (3 * j);
+    }
+    a_vmp = (unsigned)__builtin_amdgcn_readfirstlane((int)v);
   }
   unsigned b_off[B_INSTR];
 #pragma unroll
@@ -1718,10 +1750,14 @@ __device__ __forceinline__ void gemm_dxs_body(const GemmParams& p, const int til
   using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
   using Tt = std::true_type; using Ff = std::false_type;
 
+  T2P_STAMP(1);
   issue_b();                                            // weight tile of K-tile 0
   issue_a();                                            // stage of group 0
   for (int g = 0; g < nch * 3; ++g) {
     ktile(I0{}, Tt{}, Ff{});                            // dx = -1: requests group g + 1
+#ifdef T2P_ABLATION
+    if (g == 0) T2P_STAMP(2);
+#endif
     ktile(I1{}, Ff{}, Tt{});                            // dx =  0: only the weight tile has to be there
     ktile(I2{}, Ff{}, Ff{});                            // dx = +1
     ra_so ^= (unsigned)ASTAGE;
@@ -1730,7 +1766,20 @@ __device__ __forceinline__ void gemm_dxs_body(const GemmParams& p, const int til
     ktile(I1{}, Tt{}, Ff{});
     ra_so ^= (unsigned)ASTAGE;
   }
-  reg_epilogue<TC, BM, BN, WM, WN>(p, acc16, m0, n0, 0, 0, 1, 0, 0);
+  T2P_STAMP(3);
+#ifdef T2P_ABLATION
+  const int edbg = dbg_arg & 1024;                     // 1024: the stores go nowhere (timeline experiments)
+#else
+  const int edbg = 0;
+#endif
+  if (!(dbg_arg & 8192) && !p.c_f32 && !p.bias_m) reg_epilogue<TC, BM, BN, WM, WN, false, true>(p, acc16, m0, n0, 0, 0, 1, 0, edbg);     // (never split-K, GEGLU, up-sampled: dxs_eligible)
+  else reg_epilogue<TC, BM, BN, WM, WN>(p, acc16, m0, n0, 0, 0, 1, 0, edbg);
+#ifdef T2P_ABLATION
+  T2P_STAMP(4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  T2P_STAMP(5);
+  T2P_STAMP_RT(7);
+#endif
 }
 template <typename TC, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_dxs_kernel(const GemmParams p, const int tiles_m, const int tiles_n, const int dbg_arg) {
@@ -2339,7 +2388,7 @@ static bool dxs_eligible(const GemmParams& p, const DmaPlan& plan) {
   if (!g_dxs || p.taps != 9 || p.a_up || plan.nsplit != 1 || (plan.geom != 1 && plan.geom != 3) || g_dma_ring != 2) return false;
   if (p.nz0 * p.nz1 != 1 || p.c_frag || p.geglu) return false;
   const int BM = plan.geom == 1 ? 256 : 512, HW = p.H * p.W;
-  if (p.W % 64 != 0 || BM % p.W != 0 || HW % BM != 0 || p.M % HW != 0) return false;
+  if (p.W % 64 != 0 || (p.W & (p.W - 1)) != 0 || BM % p.W != 0 || HW % BM != 0 || p.M % HW != 0) return false;
   if ((p.CX0 + p.CX1) % 64 != 0) return false;
   return reg_epilogue_ok(p, 1, 0);            // the kernel carries the register epilogue only
 }

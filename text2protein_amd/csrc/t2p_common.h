@@ -188,6 +188,9 @@ void set_gemm_up4(bool on);
 void set_gemm_deep_ring(bool on);
 void set_gemm_fuse_shortcut(bool on);
 void set_gemm_dxs(bool on);
+#ifdef T2P_ABLATION
+int dxs_stamps_read(unsigned long long* out, int n);   // measurement builds: in-kernel timeline of gemm_dxs_kernel (gemm.hip)
+#endif
 extern bool g_qkv_fused;
 extern bool g_attn_merged, g_ffpo_merged;
 extern bool g_flash_attention;   // engine / op API: fused attention kernel where eligible
