@@ -849,6 +849,7 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
   const unsigned ldc_e = ws ? (unsigned)p.N : (unsigned)p.ldc;
   const unsigned rsz = p.r_lowp ? 2u : 4u;
   const bool nostore = (dbg & 1024) != 0;
+  const bool alpha_not_one = p.alpha != 1.0f;
   float cs[16], cq[16];                                   // GroupNorm column sums of a 64-row chunk (4 row tiles)
 
   // rows of 16-row tile i: the output row of this lane and (r_up) the half-resolution residual row
@@ -908,6 +909,9 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
           const int c = col0 + (k & 7) + 32 * (k >> 3);
           v[k] += bm + (c < p.N ? (p.bias_n ? p.bias_n[c] : 0.f) + p.bias_bn[(long)(b_first + bsel) * p.ld_bn + c] : 0.f);
         }
+      } else if constexpr (PLAIN) {                      // (no per-row bias: bm is zero)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] += bs[k];
       } else {
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] += bm + bs[k];
@@ -941,8 +945,10 @@ __device__ __forceinline__ void reg_epilogue(const GemmParams& p, f32x4_t (&acc1
       return;
     }
     if (!ws) {
+      if (!PLAIN || alpha_not_one) {                     // (x * 1 = x exactly: skipping the product changes nothing)
 #pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] *= p.alpha;
+        for (int k = 0; k < 16; ++k) v[k] *= p.alpha;
+      }
       if (p.col_stats) {
         if (row < p.M) {
 #pragma unroll
@@ -1039,7 +1045,7 @@ __device__ __forceinline__ void gemm_dma_body(const GemmParams& p, const int til
 #ifdef T2P_ABLATION
   const int dbg = dbg_arg;
 #else
-  const int dbg = dbg_arg & (128 | 256 | 4096);
+  const int dbg = dbg_arg & (128 | 256 | 4096 | 8192);
 #endif
   // NST stages for the A (activation) tile, NSTB for the B (weight) tile.  NSTB < NST gives the
   // activations -- which come from L2 / Infinity Cache -- a longer lead than the L2-hot weights
@@ -1471,7 +1477,17 @@ __device__ __forceinline__ void gemm_dma_body(const GemmParams& p, const int til
   }
 
   // REGE (16x16x32 kernels; chosen by the launcher with reg_epilogue_ok): epilogue straight from the registers
-  if constexpr (MF16 && REGE) reg_epilogue<TC, BM, BN, WM, WN, CFRAG>(p, acc16, m0, n0, z0, z1, nsplit, ks, dbg);
+  if constexpr (MF16 && REGE) {
+    // plain products (MODE 0: the attention / MLP projections, 8 K-tiles at C = 512, where the epilogue is a quarter of a tile) take the
+    // specialised form when the launch is its case; the convolution modes keep one epilogue each (code size, registers)
+    if constexpr (MODE == 0 && !CFRAG) {
+      if (nsplit == 1 && !(dbg & 8192) && !p.geglu && !p.c_f32 && !p.bias_m && !p.up_phase)
+        reg_epilogue<TC, BM, BN, WM, WN, false, true>(p, acc16, m0, n0, z0, z1, 1, 0, dbg);
+      else reg_epilogue<TC, BM, BN, WM, WN, CFRAG>(p, acc16, m0, n0, z0, z1, nsplit, ks, dbg);
+    } else {
+      reg_epilogue<TC, BM, BN, WM, WN, CFRAG>(p, acc16, m0, n0, z0, z1, nsplit, ks, dbg);
+    }
+  }
   else dma_epilogue<TC, BM, BN, WM, WN, MF16, TI, TJ>(p, smem, acc, acc16, m0, n0, z0, z1, nsplit, ks, dbg);
 }
 template <typename TC, int BM, int BN, int WM, int WN, int MODE, int NST, int NSTB = NST, bool MF16 = false, bool REGE = false>
