@@ -20,6 +20,8 @@ from helpers import FULL, CounterNoise, full_inputs, load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LONG = os.environ.get("T2P_LONG_TESTS") == "1"      # variants that only repeat a pinned figure on a second size run under T2P_LONG_TESTS=1 (suite time on the GPU box)
+long_only = pytest.mark.skipif(not LONG, reason="T2P_LONG_TESTS=1 runs it")
 OUT = os.path.join(ROOT, "gpurun_out")
 
 F32_TOL = 1e-5
@@ -182,7 +184,7 @@ RUN1000_YAML = {"cond_length": "cond_length.yml", "test_config": "test_config.ym
                 "test_config_L128": "test_config.yml"}
 
 
-@pytest.mark.parametrize("stem", ["cond_length", "test_config", "cond_length_inpainting", "test_config_L128"])
+@pytest.mark.parametrize("stem", ["cond_length", pytest.param("test_config", marks=long_only), "cond_length_inpainting", "test_config_L128"])
 def test_thousand_step_run_vs_reference(stem):
     """The horizon the metric is quoted on, pinned by the REFERENCE: complete N = 1000 runs of the reference sampler
     (tests/golden/make_golden_full.py, run1000_<stem>.npz) on counter-based noise -- cond_length.yml at L = 128 with the length
@@ -218,7 +220,7 @@ def test_thousand_step_run_vs_reference(stem):
     # the exact-f32 engine's 1000-step figure is taken on the cond_length fixture; on the others (measured in round 4 with T2P_LONG_TESTS=1:
     # cond_length_inpainting 2.1e-6, test_config at L = 128 2.0e-6, at L = 64 2.0e-6; profiles/r04_parity.json) it costs 25 - 80 s each of
     # the GPU box's time limit and runs only with T2P_LONG_TESTS=1
-    dts = ("f32", "f16") if stem == "cond_length" or os.environ.get("T2P_LONG_TESTS") == "1" else ("f16",)
+    dts = ("f32", "f16") if stem == "cond_length" or LONG else ("f16",)
     for dt in dts:
         m = _model(cfg, sd, dt)
         noise = CounterNoise(int(g["noise_seed"]))
@@ -334,7 +336,7 @@ def test_groupnorm_in_the_split_k_second_pass_matches_separate_launches(stem):
     assert d < F16_SCORE_TOL and e[1] < F16_SCORE_TOL and e[1] < 1.05 * e[0]
 
 
-@pytest.mark.parametrize("stem", ["cond_length", "test_config", "test_config_large"])
+@pytest.mark.parametrize("stem", ["cond_length", "test_config", pytest.param("test_config_large", marks=long_only)])
 def test_merged_projections_match_the_reference(stem):
     """Two products the engine forms once at load time in the 16-bit modes, both exact in real arithmetic:
     NIN_2 . NIN_3 of AttnBlockpp (the rows of its softmax sum to 1, layers.py:168-176; plan switch 32) and
@@ -440,7 +442,7 @@ def test_spatial_transformer_row_chains_match_separate_launches(stem):
         assert d[k] < F16_SCORE_TOL and e[k] < F16_SCORE_TOL and e[k] < 1.05 * e["separate"]
 
 
-@pytest.mark.parametrize("stem", ["test_config", "test_config_large"])
+@pytest.mark.parametrize("stem", ["test_config", pytest.param("test_config_large", marks=long_only)])
 def test_fragment_major_attention_operands_match_row_major(stem):
     """Plan switch 45: at the 32 x 32 level of the C = 512 configurations the q | k projection writes its k columns and the transposed
     value projection all of its output fragment-major, and the wide-head attention kernel streams them with whole cache lines per load.

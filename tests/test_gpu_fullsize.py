@@ -156,6 +156,7 @@ def test_midsize_splitk_plan_matches_unsplit(full):
     assert ea < 2e-3 and eb < 2e-3 and abs(ea - eb) < 0.2 * ea and eab < ea
 
 
+@pytest.mark.skipif(os.environ.get("T2P_LONG_TESTS") != "1", reason="superseded by the reference-pinned test_full_size_score_vs_reference[test_config_large] and test_cfg4_sampler_at_full_size; T2P_LONG_TESTS=1 runs it")
 def test_large_config_score_properties():
     """BASELINE configs[3]: test_config_large.yml at L=256 (863.3 M parameters, 3 res-blocks per level, channel
     multiplier 4 at the lowest level: AttnBlockpp runs single-head attention with d up to 1024).  The oracle is
