@@ -82,6 +82,9 @@ int t2p_engine_score_ex(t2p_engine* e, const float* x, const int32_t* labels, co
                         int batch, void* stream);
 /* bytes of device memory currently held (weights + cached activations) */
 int64_t t2p_engine_device_bytes(const t2p_engine* e);
+/* activation buffers the LAST score evaluation / set_context left checked out and the engine took back at its end: 0 after every
+ * complete evaluation (a leak check for tests); > 0 only after a call that failed half-way */
+int t2p_engine_pool_reclaimed(const t2p_engine* e);
 
 /* ---- predictor-corrector sampler ------------------------------------------------------------
  * t2p_sampler_create        <- get_sampling_fn / get_pc_sampler (sampling.py:78-104, 213-243)

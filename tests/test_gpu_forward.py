@@ -55,6 +55,35 @@ def test_missing_weight_fails_loudly():
         m(torch.zeros(1, 5, 16, 16).cuda(), torch.zeros(1).long().cuda(), torch.zeros(1, 3, 32).cuda())
 
 
+def test_failed_evaluation_returns_its_buffers_to_the_pool():
+    """An evaluation that fails half-way (here: a batch the cached text keys / values were not projected for, detected inside the
+    first SpatialTransformer block, with the skip stack and the block's temporaries checked out) must not leave those buffers checked
+    out for the lifetime of the engine: the lease scope of Engine::score takes them back (t2p_engine_pool_reclaimed > 0), the next
+    evaluation reuses them (no growth of the pool) and is bit-identical to the one before the failure."""
+    from text2protein_amd import synth
+    from text2protein_amd._lib import T2PError, check, ptr, stream_ptr
+    from text2protein_amd.model import HipScoreModel
+    cfg = cfg_tiny()
+    m = HipScoreModel(cfg, dtype="f16")
+    m.load_state_dict(synth.synth_state_dict(cfg, 0))
+    x = torch.from_numpy(synth.normal(3, "x", 2 * 5 * 16 * 16).reshape(2, 5, 16, 16)).cuda()
+    labels = torch.tensor([3, 40]).cuda()
+    ctx = synth.synth_context(2, 3, cfg.model.context_dim, 1).cuda()
+    a = m(x, labels, ctx)
+    torch.cuda.synchronize()
+    assert m.pool_reclaimed() == 0
+    held = m.device_bytes()
+    out = torch.empty(1, 5, 16, 16, device="cuda")
+    li = labels[:1].to(torch.int32).contiguous()
+    with pytest.raises(T2PError):               # one chain against a context cached for two: fails inside the network, not at the door
+        check(m.lib.t2p_engine_score_ex(m._h, ptr(x[:1].contiguous()), ptr(li), None, ptr(out), 1, stream_ptr()))
+    assert m.pool_reclaimed() > 0
+    held1 = m.device_bytes()                    # (the one-chain attempt added its own buffer sizes to the exact-size pool)
+    b = m(x, labels, ctx)
+    torch.cuda.synchronize()
+    assert m.pool_reclaimed() == 0 and m.device_bytes() == held1 and held1 - held < (1 << 20) and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
 def test_score_wide_config_matches_oracle(dtype):
     """64/128-channel maps at 32x32: the configuration where the LDS-DMA kernel carries the convolutions."""

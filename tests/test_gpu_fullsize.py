@@ -42,6 +42,7 @@ def test_full_size_score_properties(full):
     torch.cuda.synchronize()
     assert torch.isfinite(a).all()
     assert torch.equal(a, b)                                    # bitwise reproducible
+    assert m32.pool_reclaimed() == 0                            # every block returned its temporaries (the lease scope found none)
     # chains are independent inside the network (only the Langevin step size couples them):
     # evaluating a sample alone gives the same score as inside a batch
     for i in (0, 3):
@@ -54,6 +55,7 @@ def test_full_size_score_properties(full):
     d = m16(x, labels, ctx)
     torch.cuda.synchronize()
     assert torch.equal(c, d)
+    assert m16.pool_reclaimed() == 0 and m16.device_bytes() == (m16(x, labels, ctx), m16.device_bytes())[1]   # no leak, no growth
     err = rel_l2(c.cpu(), a.cpu())
     print(f"full-size score: f16 vs exact-f32 rel-L2 = {err:.3e}")
     assert err < 2e-3

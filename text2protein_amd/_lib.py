@@ -62,6 +62,7 @@ SIGNATURES = {
     "t2p_engine_score": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "t2p_engine_score_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "t2p_engine_device_bytes": (_i64, [_vp]),
+    "t2p_engine_pool_reclaimed": (_i, [_vp]),
     "t2p_sampler_create": (_i, [_vp, C.POINTER(SamplerConfig), _vp, _vp, C.POINTER(_vp)]),
     "t2p_sampler_set_seed": (_i, [_vp, _u64]),
     "t2p_sampler_set_norm_allreduce": (_i, [_vp, _vp, _vp, _vp]),

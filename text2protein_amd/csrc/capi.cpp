@@ -101,6 +101,7 @@ int t2p_engine_score_ex(t2p_engine* e, const float* x, const int32_t* labels, co
 }
 
 int64_t t2p_engine_device_bytes(const t2p_engine* e) { return e ? e->impl.device_bytes() : 0; }
+int t2p_engine_pool_reclaimed(const t2p_engine* e) { return e ? e->impl.pool_reclaimed() : -1; }
 
 int t2p_sampler_create(t2p_engine* e, const t2p_sampler_config* cfg, const float* g_table, const int32_t* label_table,
                        t2p_sampler** out) {

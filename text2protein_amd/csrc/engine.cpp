@@ -110,6 +110,7 @@ void* DevPool::get(size_t bytes) {
   if (it != free_.end()) {
     void* p = it->second;
     free_.erase(it);
+    if (lease_depth_) leased_.insert(p);
     return p;
   }
   void* p = nullptr;
@@ -120,12 +121,30 @@ void* DevPool::get(size_t bytes) {
   size_of_[p] = bytes;
   all_.push_back(p);
   held_ += bytes;
+  if (lease_depth_) leased_.insert(p);
   return p;
 }
 void DevPool::put(void* p) {
   if (!p) return;
   auto it = size_of_.find(p);
-  if (it != size_of_.end()) free_.emplace(it->second, p);
+  if (it == size_of_.end()) return;
+  leased_.erase(p);
+  free_.emplace(it->second, p);
+}
+void DevPool::lease_begin() {
+  if (lease_depth_++ == 0) leased_.clear();
+}
+int DevPool::lease_end() {
+  if (--lease_depth_ > 0) return 0;
+  lease_depth_ = 0;
+  const int n = (int)leased_.size();
+  for (void* p : leased_) {
+    auto it = size_of_.find(p);
+    if (it != size_of_.end()) free_.emplace(it->second, p);
+  }
+  leased_.clear();
+  last_reclaimed_ = n;
+  return n;
 }
 void* DevPool::persistent(size_t bytes) {
   bytes = round_up(std::max<size_t>(bytes, 256), 256);
@@ -1469,6 +1488,7 @@ int Engine::set_context(const float* ctx, int B, int T, hipStream_t s) {
   const bool realloc = (B != ctx_B_ || T != ctx_T_);
   const void* cx = ctx;
   void* conv = nullptr;
+  PoolLease lease(pool_);                              // (the per-layer key / value caches are handed over with keep())
   if (dt != DT_F32) {
     conv = pool_.get((size_t)B * T * D * es);
     if (!conv) return T2P_ERR_HIP;
@@ -1483,6 +1503,8 @@ int Engine::set_context(const float* ctx, int B, int T, hipStream_t s) {
       pool_.put(l.ctx_vt);
       l.ctx_k = pool_.get((size_t)B * T * C * es);
       l.ctx_vt = pool_.get((size_t)B * C * Tpad * es);
+      pool_.keep(l.ctx_k);
+      pool_.keep(l.ctx_vt);
       if (!l.ctx_k || !l.ctx_vt) return T2P_ERR_HIP;
     }
     T2P_TRY(linear(cx, false, l.a2_k, (long)B * T, l.ctx_k, false, nullptr, 1.f, s, false));
@@ -1504,6 +1526,7 @@ int Engine::score(const float* x, const int* labels, const int* step_counter, fl
   T2P_REQUIRE(x && out && B > 0 && (labels || step_counter), "score arguments");
   const int L = cfg_.max_res_num, HW = L * L, Cx = cfg_.num_channels, N = cfg_.num_scales;
   const int R = labels ? B : 1;
+  PoolLease lease(pool_);                              // whatever an early return below leaves checked out goes back to the pool
   g_tap_counter = 0;
   std::unique_ptr<LayerScope> pre_scope(new LayerScope("pre,pre," + std::to_string(L) + "," + std::to_string(Cx) + "," + std::to_string(nf_), s));
   POOL_GET(emb, float*, (size_t)R * nf_ * 4);

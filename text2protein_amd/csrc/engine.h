@@ -4,6 +4,7 @@
 #include <memory>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/t2p.h"
@@ -20,11 +21,28 @@ class DevPool {
   void put(void* p);
   size_t held_bytes() const { return held_; }
   void* persistent(size_t bytes);  // never returned to the free lists (weights, tables)
+  // Lease scope of one evaluation: every buffer taken between lease_begin and lease_end that has not been put back (or handed over
+  // with keep()) by then is returned to the free lists by lease_end -- an early return anywhere inside a block cannot leave buffers
+  // checked out for the lifetime of the engine.  lease_end returns how many it had to reclaim (0 on every complete evaluation).
+  void lease_begin();
+  int lease_end();
+  void keep(void* p) { leased_.erase(p); }   // the buffer outlives the scope (cached text keys / values)
+  int last_reclaimed() const { return last_reclaimed_; }
  private:
   std::multimap<size_t, void*> free_;
   std::unordered_map<void*, size_t> size_of_;
   std::vector<void*> all_;
+  std::unordered_set<void*> leased_;
+  int lease_depth_ = 0, last_reclaimed_ = 0;
   size_t held_ = 0;
+};
+// RAII form: the scope of Engine::score / Engine::set_context
+struct PoolLease {
+  explicit PoolLease(DevPool& p) : pool(p) { pool.lease_begin(); }
+  ~PoolLease() { pool.lease_end(); }
+  PoolLease(const PoolLease&) = delete;
+  PoolLease& operator=(const PoolLease&) = delete;
+  DevPool& pool;
 };
 
 struct HostTensor {
@@ -118,6 +136,7 @@ class Engine {
   int score(const float* x, const int* labels, const int* step_counter, float* out, int B, hipStream_t s,
             const float* labels_f = nullptr, const int* label_table = nullptr, const float* label_f_table = nullptr);
   int64_t device_bytes() const { return (int64_t)pool_.held_bytes(); }
+  int pool_reclaimed() const { return pool_.last_reclaimed(); }
   const t2p_model_config& cfg() const { return cfg_; }
   DevPool& pool() { return pool_; }
   int dtype() const { return cfg_.compute_dtype; }

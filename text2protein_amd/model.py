@@ -171,6 +171,10 @@ class HipScoreModel:
     def device_bytes(self):
         return int(self.lib.t2p_engine_device_bytes(self._h))
 
+    def pool_reclaimed(self):
+        """Activation buffers the last evaluation left checked out and the engine took back (0 after every complete evaluation)."""
+        return int(self.lib.t2p_engine_pool_reclaimed(self._h))
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):
