@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--B", type=int, default=32); ap.add_argument("--H", type=int, default=128); ap.add_argument("--W", type=int, default=128)
     ap.add_argument("--cin", type=int, default=128); ap.add_argument("--cout", type=int, default=128)
     ap.add_argument("--plan", default="")
+    ap.add_argument("--tile", type=int, default=0, help="rows of a tile when the plan selects another kernel than the default (256: gemm_dxs2_kernel)")
     ap.add_argument("--dbg", type=int, default=0, help="ablation bits (1024: the epilogue's stores go nowhere)")
     a = ap.parse_args()
     lib = _lib.load_ablation()
@@ -40,6 +41,8 @@ def main():
     st = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 8).astype(np.int64)
     st = st[st[:, 0] > 0]
     ntile = (a.B * a.H * a.W + 511) // 512 if a.cout <= 128 else (a.B * a.H * a.W // 256) * ((a.cout + 255) // 256)
+    if a.tile:
+        ntile = a.B * a.H * a.W // a.tile
     st = st[:min(ntile, len(st))]         # every launch of this process had the same grid: the stamps are the last launch's
     clk = np.median((st[:, 5] - st[:, 0]) / np.maximum(st[:, 7] - st[:, 6], 1)) * 100e6      # shader Hz
     names = ["set-up (entry -> first DMA issue)", "first stage lands + first K-tile", "K loop (rest)", "epilogue: compute + issue stores", "store drain"]
@@ -48,7 +51,7 @@ def main():
     tot = (st[:, 5] - st[:, 0])
     for k, nm in enumerate(names):
         print(f"  {nm:38s} median {np.median(d[:, k]) / clk * 1e6:7.2f} us  ({np.median(d[:, k]) / np.median(tot) * 100:4.1f} % of a tile)   p90 {np.percentile(d[:, k], 90) / clk * 1e6:7.2f}")
-    print(f"  tile total median {np.median(tot) / clk * 1e6:.2f} us; tiles per CU slot {len(st) / 256:.2f}; sum of medians x rounds {np.median(tot) / clk * 1e6 * np.ceil(len(st) / 256):.1f} us")
+    print(f"  tile total median {np.median(tot) / clk * 1e6:.2f} us; tiles per CU {len(st) / 256:.2f}; sum of medians x rounds {np.median(tot) / clk * 1e6 * np.ceil(len(st) / 256):.1f} us")
 
 
 if __name__ == "__main__":
