@@ -125,7 +125,7 @@ def fixture(name):
     if case.get("full_size"):        # the reference's OWN YAML for the reference model (the repo's configs/ hold views of it with the same values)
         import yaml
         from text2protein_amd.config import finalize_config
-        with open(os.path.join("/root/reference", "configs", "cond_length.yml")) as f:
+        with open(os.path.join("/root/reference", "configs", case.get("yaml", "cond_length.yml"))) as f:
             cfg_ref = finalize_config(yaml.safe_load(f), **{"data.max_res_num": cfg.data.max_res_num, "model.num_scales": cfg.model.num_scales})
         cfg_ref.device = "cpu"
         for k in ("nf", "ch_mult", "num_res_blocks", "attn_resolutions", "dropout", "ema_rate", "condition", "n_heads", "context_dim"):
@@ -141,7 +141,10 @@ def fixture(name):
     # the oracle's restatement through its own functional forward
     loss_o, raw_o, P_o, st_o = oracle_step(cfg, case, inp, r["sd"])
     e_loss = abs(float(loss_o) - float(r["loss"])) / abs(float(r["loss"]))
-    e_g = max(float((raw_o[n] - r["grads"][n]).norm() / r["grads"][n].norm().clamp_min(1e-30)) for n in names)
+    # (a gradient that is zero in exact arithmetic -- the key bias of an AttnBlockpp -- is rounding noise on both sides, and with several
+    # threads not the same noise twice: differences are held against max(|tensor|, 3e-5 of the whole gradient's norm), as in the tests)
+    gtot = float(torch.sqrt(sum((g.double() ** 2).sum() for g in r["grads"].values())))
+    e_g = max(float((raw_o[n] - r["grads"][n]).norm() / r["grads"][n].norm().clamp_min(3e-5 * gtot)) for n in names)
     e_p = max(float((P_o[n].detach() - r["post"][n]).norm() / r["post"][n].norm()) for n in names)
     e_e = max(float((st_o["ema"][n] - r["ema"][n]).norm() / r["ema"][n].norm()) for n in names)
     moved = max(float((r["post"][n] - r["sd"][n]).abs().max()) for n in names)
@@ -161,6 +164,6 @@ def fixture(name):
 
 
 if __name__ == "__main__":
-    torch.set_num_threads(2)
+    torch.set_num_threads(int(os.environ.get("T2P_GOLDEN_THREADS", "2")))
     for nm in (sys.argv[1:] or list(TRAIN_CASES)):
         fixture(nm)

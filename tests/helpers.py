@@ -113,11 +113,22 @@ def cfg_train_cond_length():
     return load_config(os.path.join(root, "configs", "cond_length.yml"), **{"data.max_res_num": 128, "model.num_scales": 1000})
 
 
+def cfg_train_test_config():
+    """BASELINE configs[1]'s model at its real WIDTH (configs/test_config.yml: nf 256, channel multipliers up to 2, 8 heads, AttnBlockpp and
+    SpatialTransformer at three resolutions, 379.5 M parameters) on L = 64 maps (six levels down to 2 x 2), dropout as shipped (0.1), no condition."""
+    from text2protein_amd.config import load_config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return load_config(os.path.join(root, "configs", "test_config.yml"), **{"data.max_res_num": 64, "model.num_scales": 1000})
+
+
 TRAIN_CASES = {   # name -> what the fixture script and the tests share; step0 = state['step'] before the update (warm-up factor step0 / 5000)
     "train_tiny": dict(config=cfg_train_tiny, seed=3, B=2, T=3, lengths=[12, 9], step0=2000, mask_info=None),
     "train_tinyB": dict(config=cfg_train_tinyB, seed=4, B=3, T=5, lengths=[16, 11, 6], step0=7000, mask_info="1:3,6:8"),
     # full size (round 4): norms + projections of all 622 tensors, whole tensors for the small ones only (the file stays ~1 MB)
     "train_cond_length": dict(config=cfg_train_cond_length, seed=5, B=1, T=16, lengths=[100], step0=9000, mask_info=None, full_size=True),
+    # the other architecture family at its real width (C = 256 / 512, attention at three resolutions)
+    "train_test_config": dict(config=cfg_train_test_config, seed=6, B=1, T=8, lengths=[50], step0=3000, mask_info=None, full_size=True,
+                              yaml="test_config.yml"),
 }
 
 
