@@ -800,8 +800,10 @@ template <typename TC, int BM, int BN, int WM, int WN, bool CFRAG = false, bool 
 __device__ __forceinline__ void reg_epilogue(const PT& p, f32x4_t (&acc16)[8][4], const int m0, const int n0, const int z0,
                                              const int z1, const int nsplit, const int ks, const int dbg) {
   if ((dbg & 1) && acc16[0][0][0] != 123.456f) return;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int tx = threadIdx.x;
+  asm volatile("" : "+v"(tx));       // nothing lane-derived of the epilogue is computed before the K loop and kept across it (registers)
+  const int lane = tx & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tx >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int l16 = lane & 15, g4 = lane >> 4;
   const int HW = p.H * p.W;
@@ -1687,18 +1689,18 @@ __device__ __forceinline__ void gemm_dxs_body(const GemmParams& p, const int til
   // fragment read offsets: lane (r = lane & 15, g = lane >> 4) reads 16 bytes of row (wave rows + r + dx) at logical chunk 4 ks + g;
   // 16-row tile i is i * 2048 bytes further with the same swizzle term (immediate offset).  Rows -1 / BM of a stage are read only by
   // lanes the edge masks zero (they lie in the neighbouring ring stage / past the allocation, where LDS reads return zero).
-  unsigned a16[3][2], b16[2];
+  // (the second 32-deep step reads chunk 4 + g: the same offset with bit 6 flipped, (4 | g) ^ x = (g ^ x) ^ 4 -- one XOR per K-tile
+  // instead of a second register per offset: four registers fewer through the K loop)
+  unsigned a16[3], b16;
   {
     const int r = lane & 15, g = lane >> 4;
     const int rb = wn * (BN / WN) + r;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       const int ra = wm * (BM / WM) + r + d - 1;         // (-1 for the first lane of the first wave row under dx = -1)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) a16[d][ks] = (unsigned)(ARING + ra * 128 + (((4 * ks + g) ^ (ra & 6)) << 4));
+      a16[d] = (unsigned)(ARING + ra * 128 + ((g ^ (ra & 6)) << 4));
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) b16[ks] = (unsigned)(rb * 128 + (((4 * ks + g) ^ ((rb >> 1) & 7)) << 4));
+    b16 = (unsigned)(rb * 128 + ((g ^ ((rb >> 1) & 7)) << 4));
   }
   // image-row edges inside this wave's 128 rows (W % 64 == 0: only these four tiles can hold one)
   const int rowb = m0 + wm * (BM / WM);
@@ -1739,7 +1741,7 @@ __device__ __forceinline__ void gemm_dxs_body(const GemmParams& p, const int til
     const unsigned sa_off = lds_base + ra_so, sb_off = lds_base + rb_so;
     rb_so ^= (unsigned)BSTAGE;
     u32x4_t B0[4], B1[4], AL[4], AH[4];
-    const unsigned aa0 = sa_off + a16[DX][0], aa1 = sa_off + a16[DX][1], bb0 = sb_off + b16[0], bb1 = sb_off + b16[1];
+    const unsigned aa0 = sa_off + a16[DX], aa1 = sa_off + (a16[DX] ^ 64u), bb0 = sb_off + b16, bb1 = sb_off + (b16 ^ 64u);
     if (early) {
       if (more_b) issue_b();
       if (more_a) issue_a();
